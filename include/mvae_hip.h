@@ -1,0 +1,141 @@
+/*
+ * mvae_hip.h -- C ABI of libmvae_hip.so, the MI355X (gfx950) implementation of the multiscale-VAE
+ * train-step hot path.
+ *
+ * The reference (NikolasMarkou/multiscale_variational_autoencoder) has NO native / FFI boundary: its
+ * arithmetic is dispatched by Keras 2.4.3 into TensorFlow 2.3.1 when
+ *     mvae/multiscale_vae.py:550-557   self._model_trainable.fit(x, x, ...)            (train step)
+ *     mvae/multiscale_vae.py:238-257   encoder / decoder keras.Model.predict           (inference)
+ * run the static graph that mvae/multiscale_vae.py:73-288 and mvae/layer_blocks.py:418-462,556-648,
+ * 893-1050 describe.  This header is therefore the boundary the build defines for that one path
+ * (SURVEY.md section 8(b)); each entry point names the reference lines whose work it replaces.  The
+ * Python facade `multiscale_variational_autoencoder_amd.MultiscaleVAE` (same constructor / compile /
+ * train surface as mvae.MultiscaleVAE) binds exactly these symbols through ctypes; INTEGRATION.md shows
+ * the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++ / torch / HIP types in any signature (streams are `void*`
+ *     holding a hipStream_t; NULL = the default stream).
+ *   - every function returns 0 on success and a negative MVAE_E_* code on failure; nothing throws or
+ *     aborts across the ABI; mvae_last_error() gives the text.
+ *   - all device buffers are CALLER-owned (the Python host allocates them with torch so the flat
+ *     gradient arena can be handed to torch.distributed/RCCL as one tensor); the handle owns only host
+ *     metadata.  All tensors are float32, images NHWC (reference: Keras channels_last).
+ *   - all work is enqueued asynchronously on the given stream; no hidden synchronisation.
+ *   - a handle is bound to one device and is not thread-safe (data parallel = one process per GPU).
+ */
+#ifndef MVAE_HIP_H
+#define MVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVAE_ABI_VERSION 1
+#define MVAE_MAX_LEVELS 16
+#define MVAE_MAX_BLOCKS 16
+#define MVAE_NAME_CAP 96
+
+#define MVAE_OK 0
+#define MVAE_E_INVALID (-1)   /* bad argument / configuration (Python facade raises ValueError) */
+#define MVAE_E_STATE (-2)     /* call order: not bound, backward without training forward, ...  */
+#define MVAE_E_HIP (-3)       /* a HIP runtime call or kernel launch failed                      */
+#define MVAE_E_NOMEM (-4)     /* caller-provided workspace too small                             */
+
+#define MVAE_REG_NONE 0
+#define MVAE_REG_L1 1         /* keras "l1": 0.01 * sum |w|   (layer_blocks.py:14)              */
+#define MVAE_REG_L2 2         /* keras "l2": 0.01 * sum w^2   (multiscale_vae.py:63-64)         */
+
+/* Constructor arguments of MultiscaleVAE (multiscale_vae.py:12-26), flattened. */
+typedef struct mvae_config {
+  int32_t abi_version;                       /* MVAE_ABI_VERSION */
+  int32_t input_h, input_w, input_c;         /* input_dims (HxWxC, channels_index = 2) */
+  int32_t levels;                            /* len(z_dims), >= 2 */
+  int32_t z_dims[MVAE_MAX_LEVELS];
+  int32_t enc_n;                             /* len(encoder["filters"]) */
+  int32_t enc_filters[MVAE_MAX_BLOCKS];
+  int32_t enc_kh[MVAE_MAX_BLOCKS], enc_kw[MVAE_MAX_BLOCKS];
+  int32_t enc_sh[MVAE_MAX_BLOCKS], enc_sw[MVAE_MAX_BLOCKS];
+  int32_t dec_n;                             /* decoder dict (already reversed by the caller when None) */
+  int32_t dec_filters[MVAE_MAX_BLOCKS];
+  int32_t dec_kh[MVAE_MAX_BLOCKS], dec_kw[MVAE_MAX_BLOCKS];
+  int32_t dec_sh[MVAE_MAX_BLOCKS], dec_sw[MVAE_MAX_BLOCKS];
+  float min_value, max_value;                /* value range, multiscale_vae.py:65-66 */
+  float sample_std;                          /* stddev of the sampling epsilon, :67 */
+  int32_t max_batch;                         /* largest batch any later call will pass */
+} mvae_config;
+
+typedef struct mvae_handle mvae_handle;
+
+/* One batch through the graph.  Device pointers; nullable members are optional. */
+typedef struct mvae_step_io {
+  const float* x;          /* [B,H,W,C] in [min_value,max_value]                                   */
+  int32_t batch;           /* B <= max_batch                                                       */
+  int32_t training;        /* 1: noise + dropout + batch-statistics BN (model_trainable.fit);      */
+                           /* 0: inference (model.predict): no noise/dropout, moving statistics    */
+  const float* eps;        /* [B,sum z] epsilon ALREADY scaled by sample_std, or NULL -> Philox    */
+  const float* noise;      /* [B,H,W,C] standard normal for GaussianNoise, or NULL -> Philox       */
+  const float* keep_mask;  /* [B,C] 1/0 keep mask of SpatialDropout2D(0.1), or NULL -> Philox      */
+  uint64_t seed;           /* Philox seed for whatever is not injected                             */
+  float* recon;            /* out [B,H,W,C] reconstruction in [min,max] (nullable)                 */
+  float* mu;               /* out [B,sum z] (nullable)                                             */
+  float* log_var;          /* out [B,sum z] (nullable)                                             */
+  float* z;                /* out [B,sum z] sampled latents (nullable)                             */
+  float* losses;           /* out [B, 3+levels]: vae_r_loss, vae_r_experimental_loss, kl,          */
+                           /*     kl_scale_0.. (multiscale_vae.py:453-488) (nullable)              */
+} mvae_step_io;
+
+/* ---- life cycle: replaces MultiscaleVAE.__init__/_build (multiscale_vae.py:12-288); host only ---- */
+int mvae_create(const mvae_config* cfg, mvae_handle** out);
+void mvae_destroy(mvae_handle* h);
+const char* mvae_last_error(const mvae_handle* h);      /* h may be NULL: error of the last failed create */
+int mvae_abi_version(void);
+
+/* ---- tables: the layer/variable inventory Keras builds ---- */
+int64_t mvae_param_count(const mvae_handle* h);         /* number of trainable tensors            */
+int64_t mvae_param_elems(const mvae_handle* h);         /* floats in the parameter arena (padded) */
+int mvae_param_info(const mvae_handle* h, int64_t i, char* name, int32_t name_cap,
+                    int64_t shape[4], int32_t* ndim, int64_t* offset, int32_t* reg);
+int64_t mvae_state_count(const mvae_handle* h);         /* BatchNorm moving mean / variance tensors */
+int64_t mvae_state_elems(const mvae_handle* h);
+int mvae_state_info(const mvae_handle* h, int64_t i, char* name, int32_t name_cap,
+                    int64_t* elems, int64_t* offset);
+int64_t mvae_latent_dim(const mvae_handle* h);          /* sum(z_dims) */
+int64_t mvae_reduce_elems(const mvae_handle* h);        /* floats in the reduce arena:                     */
+                                                        /* [grads P | BN batch statistics S | metrics]      */
+int64_t mvae_metrics_offset(const mvae_handle* h);      /* offset of the metrics block in the reduce arena:  */
+                                                        /* [count, sum r, sum r_exp, sum kl, sum kl_s..]     */
+int64_t mvae_workspace_bytes(const mvae_handle* h);     /* activations + scratch for max_batch               */
+
+/* ---- binding caller-owned device memory ---- */
+int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena, float* accum,
+              float* state, void* workspace, int64_t workspace_bytes);
+
+/* ---- the hot path ---- */
+/* forward: input_transform + encoders + sampling + decoders + merge + losses
+ *          (multiscale_vae.py:129-160, 292-315, 319-433, 204-224, 453-488). */
+int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream);
+/* backward of mean_B(r_factor * r_exp + kl_factor * kl) w.r.t. every trainable tensor; fills the
+ * gradient part of the reduce arena (regularisers are added by mvae_apply_adagrad).  What
+ * keras.Model.fit derives by autodiff from compile()'s vae_loss (multiscale_vae.py:491-504). */
+int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream);
+/* g = grad_scale * g + d(reg)/dw ; per-variable clipnorm ; Adagrad (a0 = 0.1 set by the host) ;
+ * BN moving statistics update from the (reduced) batch statistics (multiscale_vae.py:497-499). */
+int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_scale, void* stream);
+/* forward + backward + apply on one device (keras train_on_batch). */
+int mvae_train_step(mvae_handle* h, const mvae_step_io* io, float r_factor, float kl_factor, float lr,
+                    float clip_norm, void* stream);
+/* sum of the Keras regularisation losses (added to the reported `loss`) -> 1 float on the device. */
+int mvae_reg_loss(mvae_handle* h, float* out_dev, void* stream);
+/* decoder model (multiscale_vae.py:247-257): z [B,sum z] -> recon [B,H,W,C], inference mode. */
+int mvae_decode(mvae_handle* h, const float* z, int32_t batch, float* recon, void* stream);
+
+/* ---- debugging / parity: look up a saved intermediate of the last forward by name ---- */
+int mvae_tensor_lookup(const mvae_handle* h, const char* name, float** ptr, int64_t* elems_per_image);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVAE_HIP_H */

@@ -1,0 +1,147 @@
+// kernels.h -- launcher prototypes of the gfx950 kernels behind libmvae_hip.so.
+// Everything is float32, NHWC.  All launchers enqueue on `s` and never synchronise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mvae {
+
+// Geometry of a strided 'SAME' convolution in "F-form coordinates": the BIG side [B,IH,IW,CI] is the
+// conv input, the SMALL side [B,OH,OW,CO] its output; weights are [KH,KW,CI,CO].  A Keras Conv2D uses
+// it as is (kernel HWIO); a Keras Conv2DTranspose is the adjoint map small->big and its kernel
+// (kh,kw,out,in) is the very same [KH,KW,CI(big),CO(small)] array (layer_blocks.py:946-951).
+struct ConvGeom {
+  int B, IH, IW, CI, OH, OW, CO, KH, KW, SH, SW, PT, PL;
+};
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_HSIG = 3 };
+
+struct PreOp {               // transform applied to the BIG-side operand when it is read
+  const float* gate;         // [B,CI]  multiply (squeeze-excite gate), or null
+  const float* scale;        // [CI]    per-channel affine (folded BatchNorm), or null
+  const float* shift;        // [CI]
+};
+
+// ---- RNG (Philox4x32-10) ----
+void launch_rng_normal(float* out, int64_t n, float stddev, uint64_t seed, uint32_t stream_id, hipStream_t s);
+void launch_rng_keepmask(float* out, int64_t n, float p_drop, uint64_t seed, uint32_t stream_id, hipStream_t s);
+
+// ---- input transform (multiscale_vae.py:129-160, 292-315) ----
+void launch_prep(const float* x, const float* noise, const float* keep, float* out, int B, int H, int W, int C,
+                 float v0, float v1, float noise_std, float keep_scale, hipStream_t s);
+void launch_blur_split(const float* in, float* band, float* down, int B, int H, int W, int C, hipStream_t s);
+
+// ---- convolutions ----
+// small = act(conv(pre(big)) + bias) + residual
+void launch_conv_f(const float* big, const float* w, const float* bias, const float* residual, float* small,
+                   ConvGeom g, PreOp pre, int act, hipStream_t s);
+// big = convT(small) + bias + residual      (conv backward-data / Conv2DTranspose forward)
+void launch_conv_t(const float* small, const float* w, const float* bias, const float* residual, float* big,
+                   ConvGeom g, hipStream_t s);
+// dW[kh,kw,ci,co] += sum pre(big) * small      (dW pre-zeroed by the caller)
+void launch_conv_wgrad(const float* big, const float* small, float* dW, ConvGeom g, PreOp pre, hipStream_t s);
+// ELU backward in place: d *= (y > 0 ? 1 : y + 1)
+void launch_elu_bwd(float* d, const float* y, int64_t n, hipStream_t s);
+
+// depthwise 3x3 stride 1 SAME + bias + ReLU (layer_blocks.py:604-614)
+void launch_dw_fwd(const float* in, const float* w, const float* b, float* out, int B, int H, int W, int C,
+                   hipStream_t s);
+// dx = dwT(dy) * (mask_src > 0)
+void launch_dw_bwd_data(const float* dy, const float* w, const float* mask_src, float* dx, int B, int H, int W,
+                        int C, hipStream_t s);
+// dW[3,3,C] += sum in_shifted * dy ; db[C] += sum dy
+void launch_dw_wgrad(const float* in, const float* dy, float* dW, float* db, int B, int H, int W, int C,
+                     hipStream_t s);
+
+// ---- reductions over pixels ----
+// out[b,c] = scale * sum_hw x[b,hw,c]
+void launch_spatial_sum(const float* x, float* out, int B, int64_t HW, int C, float scale, hipStream_t s);
+// out[b,c] = sum_hw a*b
+void launch_spatial_dot(const float* a, const float* b, float* out, int B, int64_t HW, int C, hipStream_t s);
+// out[c] += sum_m x[m,c]
+void launch_colsum(const float* x, float* out, int64_t M, int C, hipStream_t s);
+// out[c] += sum_m (x[m,c]-mean[c])^2
+void launch_colsqdev(const float* x, const float* mean, float* out, int64_t M, int C, hipStream_t s);
+// out0[c] += sum_m d ; out1[c] += sum_m d * (x-mean)*invstd
+void launch_bn_bwd_reduce(const float* d, const float* x, const float* mean, const float* invstd, float* sum_d,
+                          float* sum_dx, int64_t M, int C, hipStream_t s);
+
+// ---- MobileNetV3 / squeeze-excite pieces (layer_blocks.py:418-462, 556-648) ----
+// d = (d * g[b,c] + dgap[b,c] * inv_hw) * (t1 > 0)       in place
+void launch_mn_dt1pre(float* d, const float* t1, const float* g, const float* dgap, int B, int64_t HW, int C,
+                      float inv_hw, hipStream_t s);
+// out[b,n] = act(sum_k a[b,k] w[k,n] + bias[n])
+void launch_gemm_nn(const float* a, const float* w, const float* bias, float* out, float* out_lin, int B, int K,
+                    int N, int act, hipStream_t s);
+// out[b,k] (+)= sum_n a'[b,n] w[k,n]; hs_lin != null: a' = a * hsig'(hs_lin[b,n])
+void launch_gemm_nt(const float* a, const float* w, float* out, int B, int K, int N, const float* hs_lin,
+                    int accumulate, hipStream_t s);
+// dW[k,n] += sum_b a[b,k] g[b,n] (a optionally affine: a*a_scale[k]+a_shift[k]) ; db[n] += sum_b g[b,n]
+// g optionally multiplied by hsig'(hs_lin)
+void launch_gemm_tn(const float* a, const float* g, float* dW, float* db, int B, int K, int N,
+                    const float* a_scale, const float* a_shift, const float* hs_lin, hipStream_t s);
+// BatchNorm over the batch axis of [B,C]; training: batch statistics (written to stat_mean/var), else moving.
+void launch_bn1d_fwd(const float* x, const float* gamma, const float* beta, const float* mov_mean,
+                     const float* mov_var, float* xhat, float* invstd, float* y, float* stat_mean, float* stat_var,
+                     int B, int C, float eps, int training, hipStream_t s);
+// dv = relu'(x) * invstd * (dy*gamma - mean(dy*gamma) - xhat*mean(dy*gamma*xhat)); dgamma += ; dbeta +=
+void launch_bn1d_bwd(const float* dy, const float* xhat, const float* invstd, const float* gamma,
+                     const float* relu_src, float* dx, float* dgamma, float* dbeta, int B, int C, hipStream_t s);
+
+// ---- decoder BatchNorm (multiscale_vae.py:420-421) helpers ----
+// training: mean = sum/M, var=sqdev/M -> scale/shift, stats out; inference: from moving stats
+void launch_bn2d_finalize(const float* sum, const float* sqdev, const float* gamma, const float* beta,
+                          const float* mov_mean, const float* mov_var, float* mean, float* invstd, float* scale,
+                          float* shift, float* stat_mean, float* stat_var, int64_t M, int C, float eps, int training,
+                          hipStream_t s);
+void launch_scale_vec(float* v, float a, int n, hipStream_t s);
+// dx = scale_c * (d - sum_d/M - xhat * sum_dx/M)   in place on d ; dgamma += sum_dx ; dbeta += sum_d
+void launch_bn2d_bwd_apply(float* d, const float* x, const float* mean, const float* invstd, const float* gamma,
+                           const float* sum_d, const float* sum_dx, float* dgamma, float* dbeta, int64_t M, int C,
+                           hipStream_t s);
+
+// ---- latent head (multiscale_vae.py:358-383, 485-488) ----
+// z = mu + exp(lv) * eps ; losses[b, kl_col] = KL_s ; also strided copies into the concatenated outputs
+void launch_sample_kl(const float* mu, const float* lv, const float* eps, int eps_stride, int eps_off, float* z,
+                      float* kl_out, int kl_stride, int kl_col, int B, int Z, hipStream_t s);
+// dmu = dz + kf/B * mu ; dlv = dz * eps * exp(lv) + kf/B * 0.5 * (exp(lv) - 1)
+void launch_sample_kl_bwd(const float* dz, const float* mu, const float* lv, const float* eps, int eps_stride,
+                          int eps_off, float* dmu, float* dlv, float kf_over_b, int B, int Z, hipStream_t s);
+void launch_copy_cols(const float* src, int src_stride, int src_off, float* dst, int dst_stride, int dst_off, int B,
+                      int n, hipStream_t s);
+
+// ---- merge + loss (multiscale_vae.py:204-224, 86-94, 453-481) ----
+// fine_out = up2(coarse) + fine_in ; if recon != null also recon = clip(denorm(fine_out))
+void launch_upsample_add(const float* coarse, const float* fine_in, float* fine_out, float* recon, int B, int H,
+                         int W, int C, float v0, float v1, hipStream_t s);
+// coarse_grad = up2^T(fine_grad)
+void launch_upsample_bwd(const float* fine_grad, float* coarse_grad, int B, int h, int w, int C, hipStream_t s);
+// per image: r, r_exp -> losses[b,0..1]; signs of the channel-mean terms -> sgn[b, 2*C]
+// also losses[b,2] = sum_s losses[b,3+s] (total KL)
+void launch_loss_fwd(const float* y, const float* recon, float* losses, int loss_stride, int nscales, float* sgn,
+                     int B, int H, int W, int C, hipStream_t s);
+// du = clipmask(m) * (v1-v0)/2 * rf/B * (-sign(y-recon)/N - 0.5*(sgn_ch/(C*HW) + incrop*sgn_cc/(C*ncrop)))
+void launch_loss_bwd(const float* y, const float* recon, const float* merged, const float* sgn, float* du, int B,
+                     int H, int W, int C, float v0, float v1, float rf_over_b, hipStream_t s);
+// metrics[0] += B ; metrics[1+j] += sum_b losses[b,j]
+void launch_metrics(const float* losses, int ncol, int B, float* metrics, hipStream_t s);
+
+// ---- optimiser (multiscale_vae.py:497-499) ----
+struct ChunkDesc { int64_t offset; int32_t len; int32_t tensor; int32_t reg; int32_t pad; };
+// g = g*grad_scale + reg'(w) ; norms[tensor] += sum g^2
+void launch_opt_prepare(const float* w, float* g, const ChunkDesc* chunks, int nchunks, float* norms,
+                        float grad_scale, hipStream_t s);
+// clip per tensor ; a += g^2 ; w -= lr * g / (sqrt(a) + 1e-7)
+void launch_opt_apply(float* w, const float* g, float* a, const ChunkDesc* chunks, int nchunks, const float* norms,
+                      float lr, float clip_norm, hipStream_t s);
+// reg[0] += sum 0.01|w| or 0.01 w^2
+void launch_reg_loss(const float* w, const ChunkDesc* chunks, int nchunks, float* out, hipStream_t s);
+// moving = moving*mom + stat*stat_scale*(1-mom)*corr ; corr = n/(n-1), n = B*per_image when per_image > 0
+struct StateDesc { int64_t offset; int32_t len; float momentum; float per_image; int32_t pad; };
+void launch_state_update(float* state, const float* stats, const StateDesc* descs, int ndesc, float stat_scale,
+                         int B, hipStream_t s);
+void set_gauss_constants(const float* g9);
+void launch_bn2d_mean(const float* sum, const float* mov_mean, float* mean, int64_t M, int C, int training,
+                      hipStream_t s);
+
+}  // namespace mvae

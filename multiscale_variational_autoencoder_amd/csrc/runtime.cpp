@@ -1,0 +1,793 @@
+// runtime.cpp -- static execution plan + C ABI (include/mvae_hip.h) of libmvae_hip.so.
+//
+// mvae_create() turns the MultiscaleVAE constructor arguments into a static plan: the parameter table
+// (SURVEY.md appendix A order), a workspace layout for every saved activation, and the op sequence of
+// mvae/multiscale_vae.py:73-288.  forward()/backward() walk that plan and enqueue HIP kernels; there is
+// no autograd -- every backward step is written out against the forward it inverts.
+#include "../../include/mvae_hip.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace mvae;
+
+namespace {
+
+constexpr int kConvBaseFilters = 32;      // multiscale_vae.py:50
+constexpr float kDropout = 0.1f;          // multiscale_vae.py:58
+constexpr float kSeBnMomentum = 0.99f, kSeBnEps = 1e-3f;     // keras BatchNormalization defaults (layer_blocks.py:448)
+constexpr float kDecBnMomentum = 0.999f, kDecBnEps = 1e-4f;  // multiscale_vae.py:420-421
+constexpr int64_t kAlign = 64;            // floats; every tensor / buffer starts on a 256-byte line
+constexpr int kChunk = 8192;
+
+std::string g_create_error;
+
+struct ParamInfo { std::string name; int64_t shape[4]; int ndim; int64_t offset, elems; int reg; };
+struct StateInfo { std::string name; int64_t elems, offset; float momentum; int64_t per_image; };
+
+struct MN {
+  int c = 0, H = 0, W = 0;
+  int64_t w0, b0, wd, bd, sw0, sb0, gam, bet, sw1, sb1, w2, b2;
+  int64_t st_mean, st_var;
+  float *t0 = nullptr, *t1 = nullptr, *out = nullptr;
+  float *gap = nullptr, *s0 = nullptr, *xhat = nullptr, *s1 = nullptr, *ulin = nullptr, *g = nullptr, *invstd = nullptr;
+};
+struct Block {
+  bool has_conv = false;
+  ConvGeom cg{};          // F-form coordinates (big = high-res side)
+  int64_t cw = 0, cb = 0;
+  float* cout = nullptr;  // conv / convT output
+  MN mn;
+};
+struct Scale {
+  int H, W, C, z, z_off;
+  float *pcur = nullptr, *band = nullptr;
+  int64_t cb_w, cb_b;
+  float* e0 = nullptr;
+  std::vector<Block> enc, dec;
+  int fh, fw, fc;
+  int64_t K;
+  int64_t mu_w, mu_b, lv_w, lv_b, dd_w, dd_b;
+  float *mu = nullptr, *lv = nullptr, *zs = nullptr, *d0 = nullptr;
+  int dc;
+  int64_t bn_g, bn_b, st_bn_mean, st_bn_var, out_w, out_b;
+  float *bn_sum, *bn_sqdev, *bn_mean, *bn_invstd, *bn_scale, *bn_shift, *bn_sum_d, *bn_sum_dx;
+  float *y = nullptr, *merged = nullptr, *dy = nullptr;
+  int64_t scratch_elems = 0;
+  float* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool scratch_used[4] = {false, false, false, false};
+  int cmax = 0;
+  float *dg, *dgap, *ds1, *dv, *dz, *dmu, *dlv;
+};
+
+}  // namespace
+
+struct mvae_handle {
+  mvae_config cfg;
+  std::string err;
+  std::vector<ParamInfo> params;
+  std::vector<StateInfo> states;
+  std::map<std::string, std::pair<int64_t, int64_t>> tensors;   // name -> (workspace float offset, elems per image)
+  std::vector<Scale> scales;
+  int64_t P = 0, S = 0, Z = 0, MET = 0;
+  int64_t ws_floats = 0;
+  std::vector<ChunkDesc> chunks;
+  std::vector<StateDesc> sdescs;
+  // workspace offsets of the fixed tables / buffers
+  int64_t off_chunks = 0, off_sdescs = 0, off_norms = 0;
+  // bound memory
+  bool bound = false;
+  int device = -1;
+  float *dp = nullptr, *dr = nullptr, *da = nullptr, *ds = nullptr, *ws = nullptr;
+  ChunkDesc* d_chunks = nullptr;
+  StateDesc* d_sdescs = nullptr;
+  float* d_norms = nullptr;
+  float *xin = nullptr, *eps_buf = nullptr, *noise_buf = nullptr, *keep_buf = nullptr, *recon = nullptr,
+        *losses = nullptr, *sgn = nullptr, *reg_tmp = nullptr;
+  // last forward
+  int last_B = 0, last_train_B = 0;
+  bool last_training = false;
+  const float* last_x = nullptr;
+  const float* last_eps = nullptr;
+};
+
+namespace {
+
+int fail(mvae_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return code;
+}
+
+int64_t align_up(int64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+void same_pad(int n, int k, int s, int* out, int* before) {
+  *out = (n + s - 1) / s;
+  int total = (*out - 1) * s + k - n;
+  if (total < 0) total = 0;
+  *before = total / 2;
+}
+
+// ---- plan builder ---------------------------------------------------------------------------
+struct Builder {
+  mvae_handle* h;
+  int64_t pcur = 0, scur = 0, wcur = 0;   // parameter / state / workspace cursors (floats)
+  int maxB;
+
+  int64_t param(const std::string& name, std::initializer_list<int64_t> shape, int reg) {
+    ParamInfo p;
+    p.name = name;
+    p.ndim = (int)shape.size();
+    p.elems = 1;
+    int i = 0;
+    for (int k = 0; k < 4; ++k) p.shape[k] = 1;
+    for (int64_t d : shape) { p.shape[i++] = d; p.elems *= d; }
+    p.offset = pcur;
+    p.reg = reg;
+    pcur = align_up(pcur + p.elems);
+    h->params.push_back(p);
+    return p.offset;
+  }
+  int64_t state(const std::string& name, int64_t elems, float momentum, int64_t per_image) {
+    StateInfo s{name, elems, scur, momentum, per_image};
+    scur = align_up(scur + elems);
+    h->states.push_back(s);
+    return s.offset;
+  }
+  // workspace buffer with `per_image` floats per image (batch-scaled) or `fixed` floats
+  int64_t ws_alloc(int64_t floats) {
+    int64_t o = wcur;
+    wcur = align_up(wcur + floats);
+    return o;
+  }
+  int64_t act(const std::string& name, int64_t per_image) {
+    int64_t o = ws_alloc(per_image * maxB);
+    if (!name.empty()) h->tensors[name] = {o, per_image};
+    return o;
+  }
+};
+
+// offsets are stored as float* relative to a null base during planning and rebased at bind
+inline float* as_ptr(int64_t off) { return reinterpret_cast<float*>(static_cast<intptr_t>(off * 4 + 4096)); }
+inline float* rebase(float* p, float* base) {
+  if (!p) return nullptr;
+  intptr_t off = (reinterpret_cast<intptr_t>(p) - 4096) / 4;
+  return base + off;
+}
+
+void build_mn(Builder& b, MN& m, const std::string& p, int c, int H, int W, Scale& sc) {
+  m.c = c; m.H = H; m.W = W;
+  m.w0 = b.param(p + ".conv0.w", {1, 1, c, c}, MVAE_REG_L1);  m.b0 = b.param(p + ".conv0.b", {c}, 0);
+  m.wd = b.param(p + ".dw.w", {3, 3, c, 1}, MVAE_REG_L1);     m.bd = b.param(p + ".dw.b", {c}, 0);
+  m.sw0 = b.param(p + ".se.d0.w", {c, c}, MVAE_REG_L1);       m.sb0 = b.param(p + ".se.d0.b", {c}, 0);
+  m.gam = b.param(p + ".se.bn.gamma", {c}, 0);                m.bet = b.param(p + ".se.bn.beta", {c}, 0);
+  m.st_mean = b.state(p + ".se.bn.mean", c, kSeBnMomentum, 0);
+  m.st_var = b.state(p + ".se.bn.var", c, kSeBnMomentum, 0);
+  m.sw1 = b.param(p + ".se.d1.w", {c, c}, MVAE_REG_L1);       m.sb1 = b.param(p + ".se.d1.b", {c}, 0);
+  m.w2 = b.param(p + ".conv2.w", {1, 1, c, c}, MVAE_REG_L1);  m.b2 = b.param(p + ".conv2.b", {c}, 0);
+  int64_t hwc = (int64_t)H * W * c;
+  m.t0 = as_ptr(b.act(p + ".t0", hwc));
+  m.t1 = as_ptr(b.act(p + ".t1", hwc));
+  m.out = as_ptr(b.act(p + ".out", hwc));
+  m.gap = as_ptr(b.act(p + ".gap", c));
+  m.s0 = as_ptr(b.act(p + ".s0", c));
+  m.xhat = as_ptr(b.act(p + ".xhat", c));
+  m.s1 = as_ptr(b.act(p + ".s1", c));
+  m.ulin = as_ptr(b.act(p + ".ulin", c));
+  m.g = as_ptr(b.act(p + ".g", c));
+  m.invstd = as_ptr(b.ws_alloc(c));
+  if (hwc > sc.scratch_elems) sc.scratch_elems = hwc;
+  if (c > sc.cmax) sc.cmax = c;
+}
+
+int build_plan(mvae_handle* h) {
+  const mvae_config& c = h->cfg;
+  Builder b{h};
+  b.maxB = c.max_batch;
+  const int L = c.levels, C = c.input_c;
+
+  // fixed tables first (sizes known after the parameter pass; reserve generously afterwards) -- the
+  // tables are appended at the end instead, see below.
+  int H = c.input_h, W = c.input_w, zoff = 0;
+  h->scales.resize(L);
+  for (int s = 0; s < L; ++s) {
+    Scale& sc = h->scales[s];
+    sc.H = H; sc.W = W; sc.C = C; sc.z = c.z_dims[s]; sc.z_off = zoff;
+    zoff += sc.z;
+    char e[32], d[32];
+    snprintf(e, sizeof(e), "enc%d", s);
+    snprintf(d, sizeof(d), "dec%d", s);
+    const std::string E(e), D(d);
+    int64_t hwC = (int64_t)H * W * C;
+    sc.pcur = as_ptr(b.act("pyr" + std::to_string(s), hwC));
+    sc.band = (s == L - 1) ? sc.pcur : as_ptr(b.act("band" + std::to_string(s), hwC));
+    if (s == L - 1) h->tensors["band" + std::to_string(s)] = h->tensors["pyr" + std::to_string(s)];
+    sc.scratch_elems = hwC;
+    // ---- encoder (multiscale_vae.py:319-385)
+    sc.cb_w = b.param(E + ".conv_base.w", {3, 3, C, kConvBaseFilters}, MVAE_REG_L2);
+    sc.cb_b = b.param(E + ".conv_base.b", {kConvBaseFilters}, 0);
+    sc.e0 = as_ptr(b.act(E + ".conv_base", (int64_t)H * W * kConvBaseFilters));
+    if ((int64_t)H * W * kConvBaseFilters > sc.scratch_elems) sc.scratch_elems = (int64_t)H * W * kConvBaseFilters;
+    int ch = kConvBaseFilters, hh = H, ww = W;
+    for (int i = 0; i < c.enc_n; ++i) {
+      Block blk;
+      int f = c.enc_filters[i], kh = c.enc_kh[i], kw = c.enc_kw[i], sh = c.enc_sh[i], sw = c.enc_sw[i];
+      std::string bp = E + ".b" + std::to_string(i);
+      if (sh != 1 || sw != 1 || f != ch) {                  // layer_blocks.py:946-949
+        blk.has_conv = true;
+        ConvGeom g{};
+        g.IH = hh; g.IW = ww; g.CI = ch; g.CO = f; g.KH = kh; g.KW = kw; g.SH = sh; g.SW = sw;
+        same_pad(hh, kh, sh, &g.OH, &g.PT);
+        same_pad(ww, kw, sw, &g.OW, &g.PL);
+        blk.cg = g;
+        blk.cw = b.param(bp + ".conv.w", {kh, kw, ch, f}, MVAE_REG_L1);
+        blk.cb = b.param(bp + ".conv.b", {f}, 0);
+        hh = g.OH; ww = g.OW; ch = f;
+        blk.cout = as_ptr(b.act(bp + ".conv", (int64_t)hh * ww * ch));
+      }
+      build_mn(b, blk.mn, bp + ".mn", f, hh, ww, sc);
+      sc.enc.push_back(blk);
+    }
+    sc.fh = hh; sc.fw = ww; sc.fc = ch;
+    sc.K = (int64_t)hh * ww * ch;
+    sc.mu_w = b.param(E + ".mu.w", {sc.K, sc.z}, MVAE_REG_L2);      sc.mu_b = b.param(E + ".mu.b", {sc.z}, 0);
+    sc.lv_w = b.param(E + ".log_var.w", {sc.K, sc.z}, MVAE_REG_L2); sc.lv_b = b.param(E + ".log_var.b", {sc.z}, 0);
+    sc.mu = as_ptr(b.act(E + ".mu", sc.z));
+    sc.lv = as_ptr(b.act(E + ".log_var", sc.z));
+    sc.zs = as_ptr(b.act(E + ".z", sc.z));
+    // ---- decoder (multiscale_vae.py:389-433)
+    sc.dd_w = b.param(D + ".dense.w", {sc.z, sc.K}, MVAE_REG_L2);   sc.dd_b = b.param(D + ".dense.b", {sc.K}, 0);
+    sc.d0 = as_ptr(b.act(D + ".dense", sc.K));
+    for (int i = 0; i < c.dec_n; ++i) {
+      Block blk;
+      int f = c.dec_filters[i], kh = c.dec_kh[i], kw = c.dec_kw[i], sh = c.dec_sh[i], sw = c.dec_sw[i];
+      std::string bp = D + ".b" + std::to_string(i);
+      if (sh != 1 || sw != 1 || f != ch) {                  // layer_blocks.py:950-951, Conv2DTranspose
+        blk.has_conv = true;
+        ConvGeom g{};
+        g.OH = hh; g.OW = ww; g.CO = ch;                    // small side = convT input
+        g.IH = hh * sh; g.IW = ww * sw; g.CI = f;           // big side = convT output
+        g.KH = kh; g.KW = kw; g.SH = sh; g.SW = sw;
+        int oh, ow;
+        same_pad(g.IH, kh, sh, &oh, &g.PT);
+        same_pad(g.IW, kw, sw, &ow, &g.PL);
+        blk.cg = g;
+        blk.cw = b.param(bp + ".convT.w", {kh, kw, f, ch}, MVAE_REG_L1);
+        blk.cb = b.param(bp + ".convT.b", {f}, 0);
+        hh = g.IH; ww = g.IW; ch = f;
+        blk.cout = as_ptr(b.act(bp + ".convT", (int64_t)hh * ww * ch));
+      }
+      build_mn(b, blk.mn, bp + ".mn", f, hh, ww, sc);
+      sc.dec.push_back(blk);
+    }
+    if (hh != H || ww != W)
+      return fail(nullptr, MVAE_E_INVALID, "decoder of scale %d produces %dx%d but the scale is %dx%d", s, hh, ww, H, W);
+    sc.dc = ch;
+    sc.bn_g = b.param(D + ".bn.gamma", {ch}, 0);  sc.bn_b = b.param(D + ".bn.beta", {ch}, 0);
+    sc.st_bn_mean = b.state(D + ".bn.mean", ch, kDecBnMomentum, 0);
+    sc.st_bn_var = b.state(D + ".bn.var", ch, kDecBnMomentum, (int64_t)H * W);
+    sc.out_w = b.param(D + ".out.w", {1, 1, ch, C}, MVAE_REG_L2);   sc.out_b = b.param(D + ".out.b", {C}, 0);
+    float** small[] = {&sc.bn_sum, &sc.bn_sqdev, &sc.bn_mean, &sc.bn_invstd, &sc.bn_scale, &sc.bn_shift,
+                       &sc.bn_sum_d, &sc.bn_sum_dx};
+    for (float** p : small) *p = as_ptr(b.ws_alloc(ch));
+    sc.y = as_ptr(b.act(D + ".y", hwC));
+    sc.merged = (s == L - 1) ? sc.y : as_ptr(b.act("merged" + std::to_string(s), hwC));
+    sc.dy = as_ptr(b.act("", hwC));
+    for (int k = 0; k < 4; ++k) sc.scratch[k] = as_ptr(b.act("", sc.scratch_elems));
+    int64_t cm = sc.cmax;
+    sc.dg = as_ptr(b.act("", cm)); sc.dgap = as_ptr(b.act("", cm));
+    sc.ds1 = as_ptr(b.act("", cm)); sc.dv = as_ptr(b.act("", cm));
+    sc.dz = as_ptr(b.act("", sc.z)); sc.dmu = as_ptr(b.act("", sc.z)); sc.dlv = as_ptr(b.act("", sc.z));
+    H /= 2; W /= 2;
+  }
+  h->P = b.pcur; h->S = b.scur; h->Z = zoff;
+  h->MET = align_up(4 + L);
+  // global buffers
+  int64_t hwC = (int64_t)c.input_h * c.input_w * C;
+  h->xin = nullptr;
+  h->eps_buf = as_ptr(b.act("eps", h->Z));
+  h->noise_buf = as_ptr(b.act("noise", hwC));
+  h->keep_buf = as_ptr(b.act("keep_mask", C));
+  h->recon = as_ptr(b.act("recon", hwC));
+  h->losses = as_ptr(b.act("losses", 3 + L));
+  h->sgn = as_ptr(b.act("", 2 * C));
+  h->reg_tmp = as_ptr(b.ws_alloc(kAlign));
+  // optimiser tables
+  for (size_t t = 0; t < h->params.size(); ++t) {
+    const ParamInfo& p = h->params[t];
+    for (int64_t o = 0; o < p.elems; o += kChunk) {
+      ChunkDesc cd;
+      cd.offset = p.offset + o;
+      cd.len = (int32_t)((p.elems - o) < kChunk ? (p.elems - o) : kChunk);
+      cd.tensor = (int32_t)t; cd.reg = p.reg; cd.pad = 0;
+      h->chunks.push_back(cd);
+    }
+  }
+  for (const StateInfo& s : h->states) {
+    StateDesc sd;
+    sd.offset = s.offset; sd.len = (int32_t)s.elems; sd.momentum = s.momentum;
+    sd.per_image = (float)s.per_image;   // > 0: Bessel correction with n = B * per_image (fused 4-D BN path)
+    sd.pad = 0;
+    h->sdescs.push_back(sd);
+  }
+  h->off_chunks = b.ws_alloc((int64_t)(h->chunks.size() * sizeof(ChunkDesc) + 3) / 4);
+  h->off_sdescs = b.ws_alloc((int64_t)(h->sdescs.size() * sizeof(StateDesc) + 3) / 4);
+  h->off_norms = b.ws_alloc((int64_t)h->params.size());
+  h->ws_floats = b.wcur;
+  return MVAE_OK;
+}
+
+void rebase_all(mvae_handle* h) {
+  float* base = h->ws;
+  auto rb = [&](float*& p) { p = rebase(p, base); };
+  auto rb_mn = [&](MN& m) {
+    rb(m.t0); rb(m.t1); rb(m.out); rb(m.gap); rb(m.s0); rb(m.xhat); rb(m.s1); rb(m.ulin); rb(m.g); rb(m.invstd);
+  };
+  for (Scale& sc : h->scales) {
+    bool alias_band = sc.band == sc.pcur, alias_m = sc.merged == sc.y;
+    rb(sc.pcur);
+    if (alias_band) sc.band = sc.pcur; else rb(sc.band);
+    rb(sc.e0);
+    for (Block& b : sc.enc) { rb(b.cout); rb_mn(b.mn); }
+    for (Block& b : sc.dec) { rb(b.cout); rb_mn(b.mn); }
+    rb(sc.mu); rb(sc.lv); rb(sc.zs); rb(sc.d0);
+    rb(sc.bn_sum); rb(sc.bn_sqdev); rb(sc.bn_mean); rb(sc.bn_invstd); rb(sc.bn_scale); rb(sc.bn_shift);
+    rb(sc.bn_sum_d); rb(sc.bn_sum_dx);
+    rb(sc.y);
+    if (alias_m) sc.merged = sc.y; else rb(sc.merged);
+    rb(sc.dy);
+    for (int k = 0; k < 4; ++k) rb(sc.scratch[k]);
+    rb(sc.dg); rb(sc.dgap); rb(sc.ds1); rb(sc.dv); rb(sc.dz); rb(sc.dmu); rb(sc.dlv);
+  }
+  rb(h->eps_buf); rb(h->noise_buf); rb(h->keep_buf); rb(h->recon); rb(h->losses); rb(h->sgn); rb(h->reg_tmp);
+  h->d_chunks = reinterpret_cast<ChunkDesc*>(base + h->off_chunks);
+  h->d_sdescs = reinterpret_cast<StateDesc*>(base + h->off_sdescs);
+  h->d_norms = base + h->off_norms;
+}
+
+// ---- scratch pool (per scale, static order => stable pointers under graph capture) ----------
+float* acquire(Scale& sc) {
+  for (int k = 0; k < 4; ++k)
+    if (!sc.scratch_used[k]) { sc.scratch_used[k] = true; return sc.scratch[k]; }
+  return nullptr;
+}
+void release(Scale& sc, float* p) {
+  for (int k = 0; k < 4; ++k)
+    if (sc.scratch[k] == p) sc.scratch_used[k] = false;
+}
+
+ConvGeom geom1x1(int B, int H, int W, int ci, int co) {
+  ConvGeom g{};
+  g.B = B; g.IH = g.OH = H; g.IW = g.OW = W; g.CI = ci; g.CO = co;
+  g.KH = g.KW = g.SH = g.SW = 1; g.PT = g.PL = 0;
+  return g;
+}
+
+// ---- MobileNetV3 block (layer_blocks.py:556-648 with squeeze_excite_block :418-462) ----------
+void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipStream_t s) {
+  const float* P = h->dp;
+  float* stats = h->dr + h->P;
+  const int c = m.c;
+  ConvGeom g = geom1x1(B, m.H, m.W, c, c);
+  PreOp none{nullptr, nullptr, nullptr};
+  launch_conv_f(x, P + m.w0, P + m.b0, nullptr, m.t0, g, none, ACT_RELU, s);
+  launch_dw_fwd(m.t0, P + m.wd, P + m.bd, m.t1, B, m.H, m.W, c, s);
+  launch_spatial_sum(m.t1, m.gap, B, (int64_t)m.H * m.W, c, 1.0f / (float)(m.H * m.W), s);
+  launch_gemm_nn(m.gap, P + m.sw0, P + m.sb0, m.s0, nullptr, B, c, c, ACT_RELU, s);
+  launch_bn1d_fwd(m.s0, P + m.gam, P + m.bet, h->ds + m.st_mean, h->ds + m.st_var, m.xhat, m.invstd, m.s1,
+                  stats + m.st_mean, stats + m.st_var, B, c, kSeBnEps, training ? 1 : 0, s);
+  launch_gemm_nn(m.s1, P + m.sw1, P + m.sb1, m.g, m.ulin, B, c, c, ACT_HSIG, s);
+  PreOp gate{m.g, nullptr, nullptr};
+  launch_conv_f(m.t1, P + m.w2, P + m.b2, x, m.out, g, gate, ACT_NONE, s);
+}
+
+// returns the buffer holding d(loss)/d(block input); consumes (releases) `dout` when it is a pool buffer
+float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout, int B, hipStream_t s) {
+  const float* P = h->dp;
+  float* G = h->dr;
+  const int c = m.c;
+  const int64_t HW = (int64_t)m.H * m.W, M = HW * B;
+  ConvGeom g = geom1x1(B, m.H, m.W, c, c);
+  PreOp none{nullptr, nullptr, nullptr};
+  float* bufB = acquire(sc);
+  launch_conv_t(dout, P + m.w2, nullptr, nullptr, bufB, g, s);                        // dt2 = dout . W2^T
+  launch_spatial_dot(bufB, m.t1, sc.dg, B, HW, c, s);                                  // dg = sum_hw dt2 * t1
+  PreOp gate{m.g, nullptr, nullptr};
+  launch_conv_wgrad(m.t1, dout, G + m.w2, g, gate, s);                                 // dW2 = (t1*g)^T dout
+  launch_colsum(dout, G + m.b2, M, c, s);
+  // squeeze-excite backward
+  launch_gemm_tn(m.xhat, sc.dg, G + m.sw1, G + m.sb1, B, c, c, P + m.gam, P + m.bet, m.ulin, s);
+  launch_gemm_nt(sc.dg, P + m.sw1, sc.ds1, B, c, c, m.ulin, 0, s);
+  launch_bn1d_bwd(sc.ds1, m.xhat, m.invstd, P + m.gam, m.s0, sc.dv, G + m.gam, G + m.bet, B, c, s);
+  launch_gemm_tn(m.gap, sc.dv, G + m.sw0, G + m.sb0, B, c, c, nullptr, nullptr, nullptr, s);
+  launch_gemm_nt(sc.dv, P + m.sw0, sc.dgap, B, c, c, nullptr, 0, s);
+  // through the gate multiply, the global average pool and the depthwise ReLU
+  launch_mn_dt1pre(bufB, m.t1, m.g, sc.dgap, B, HW, c, 1.0f / (float)HW, s);
+  launch_dw_wgrad(m.t0, bufB, G + m.wd, G + m.bd, B, m.H, m.W, c, s);
+  float* bufC = acquire(sc);
+  launch_dw_bwd_data(bufB, P + m.wd, m.t0, bufC, B, m.H, m.W, c, s);                   // dt0pre
+  launch_conv_wgrad(x, bufC, G + m.w0, g, none, s);
+  launch_colsum(bufC, G + m.b0, M, c, s);
+  launch_conv_t(bufC, P + m.w0, nullptr, dout, bufB, g, s);                            // da = dt0pre.W0^T + dout
+  release(sc, bufC);
+  release(sc, dout);
+  return bufB;
+}
+
+void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_t s) {
+  const float* P = h->dp;
+  float* stats = h->dr + h->P;
+  launch_gemm_nn(sc.zs, P + sc.dd_w, P + sc.dd_b, sc.d0, nullptr, B, sc.z, (int)sc.K, ACT_NONE, s);
+  const float* x = sc.d0;
+  for (Block& blk : sc.dec) {
+    if (blk.has_conv) {
+      ConvGeom g = blk.cg; g.B = B;
+      launch_conv_t(x, P + blk.cw, P + blk.cb, nullptr, blk.cout, g, s);
+      x = blk.cout;
+    }
+    mn_forward(h, blk.mn, x, B, training, s);
+    x = blk.mn.out;
+  }
+  const int64_t M = (int64_t)B * sc.H * sc.W;
+  if (training) {
+    (void)hipMemsetAsync(sc.bn_sum, 0, sizeof(float) * sc.dc, s);
+    (void)hipMemsetAsync(sc.bn_sqdev, 0, sizeof(float) * sc.dc, s);
+    launch_colsum(x, sc.bn_sum, M, sc.dc, s);
+    launch_bn2d_mean(sc.bn_sum, nullptr, sc.bn_mean, M, sc.dc, 1, s);
+    launch_colsqdev(x, sc.bn_mean, sc.bn_sqdev, M, sc.dc, s);
+  } else {
+    launch_bn2d_mean(nullptr, h->ds + sc.st_bn_mean, sc.bn_mean, M, sc.dc, 0, s);
+  }
+  launch_bn2d_finalize(sc.bn_sum, sc.bn_sqdev, P + sc.bn_g, P + sc.bn_b, h->ds + sc.st_bn_mean, h->ds + sc.st_bn_var,
+                       sc.bn_mean, sc.bn_invstd, sc.bn_scale, sc.bn_shift, stats + sc.st_bn_mean,
+                       stats + sc.st_bn_var, M, sc.dc, kDecBnEps, training ? 1 : 0, s);
+  ConvGeom g = geom1x1(B, sc.H, sc.W, sc.dc, sc.C);
+  PreOp bn{nullptr, sc.bn_scale, sc.bn_shift};
+  launch_conv_f(x, P + sc.out_w, P + sc.out_b, nullptr, sc.y, g, bn, ACT_NONE, s);
+}
+
+void merge_forward(mvae_handle* h, int B, float* recon, hipStream_t s) {
+  const mvae_config& c = h->cfg;
+  const int L = c.levels;
+  for (int i = L - 2; i >= 0; --i) {
+    Scale& sc = h->scales[i];
+    launch_upsample_add(h->scales[i + 1].merged, sc.y, sc.merged, i == 0 ? recon : nullptr, B, sc.H, sc.W, sc.C,
+                        c.min_value, c.max_value, s);
+  }
+}
+
+int check_launch(mvae_handle* h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, MVAE_E_HIP, "%s: %s", what, hipGetErrorString(e));
+  return MVAE_OK;
+}
+
+}  // namespace
+
+// ==================================================================================================
+// C ABI
+// ==================================================================================================
+extern "C" {
+
+int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
+
+const char* mvae_last_error(const mvae_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mvae_create(const mvae_config* cfg, mvae_handle** out) {
+  if (!cfg || !out) return fail(nullptr, MVAE_E_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != MVAE_ABI_VERSION) return fail(nullptr, MVAE_E_INVALID, "ABI version mismatch");
+  if (cfg->levels < 2 || cfg->levels > MVAE_MAX_LEVELS)
+    return fail(nullptr, MVAE_E_INVALID, "len(z_dims) must be in [2, %d] (the reference merge model needs >= 2 levels)",
+                MVAE_MAX_LEVELS);
+  for (int i = 0; i < cfg->levels; ++i)
+    if (cfg->z_dims[i] <= 0) return fail(nullptr, MVAE_E_INVALID, "z_dims elements should be > 0");
+  if (cfg->input_h <= 0 || cfg->input_w <= 0 || cfg->input_c <= 0 || cfg->input_c > 8)
+    return fail(nullptr, MVAE_E_INVALID, "input_dims must be positive with at most 8 channels");
+  int div = 1 << (cfg->levels - 1);
+  if (cfg->input_h % div || cfg->input_w % div)
+    return fail(nullptr, MVAE_E_INVALID, "input height/width must be divisible by 2^(levels-1) = %d", div);
+  if (cfg->enc_n <= 0 || cfg->enc_n > MVAE_MAX_BLOCKS || cfg->dec_n <= 0 || cfg->dec_n > MVAE_MAX_BLOCKS)
+    return fail(nullptr, MVAE_E_INVALID, "encoder/decoder lists must have 1..%d entries", MVAE_MAX_BLOCKS);
+  for (int i = 0; i < cfg->enc_n; ++i)
+    if (cfg->enc_filters[i] <= 0 || cfg->enc_kh[i] <= 0 || cfg->enc_kw[i] <= 0 || cfg->enc_sh[i] <= 0 ||
+        cfg->enc_sw[i] <= 0)
+      return fail(nullptr, MVAE_E_INVALID, "Filters should be > 0 (encoder entry %d)", i);
+  for (int i = 0; i < cfg->dec_n; ++i)
+    if (cfg->dec_filters[i] <= 0 || cfg->dec_kh[i] <= 0 || cfg->dec_kw[i] <= 0 || cfg->dec_sh[i] <= 0 ||
+        cfg->dec_sw[i] <= 0)
+      return fail(nullptr, MVAE_E_INVALID, "Filters should be > 0 (decoder entry %d)", i);
+  if (!(cfg->max_value > cfg->min_value)) return fail(nullptr, MVAE_E_INVALID, "max_value must exceed min_value");
+  if (cfg->max_batch <= 0) return fail(nullptr, MVAE_E_INVALID, "max_batch must be > 0");
+  mvae_handle* h = new mvae_handle();
+  h->cfg = *cfg;
+  int rc = build_plan(h);
+  if (rc != MVAE_OK) { delete h; return rc; }
+  *out = h;
+  return MVAE_OK;
+}
+
+void mvae_destroy(mvae_handle* h) { delete h; }
+
+int64_t mvae_param_count(const mvae_handle* h) { return h ? (int64_t)h->params.size() : -1; }
+int64_t mvae_param_elems(const mvae_handle* h) { return h ? h->P : -1; }
+int mvae_param_info(const mvae_handle* h, int64_t i, char* name, int32_t name_cap, int64_t shape[4], int32_t* ndim,
+                    int64_t* offset, int32_t* reg) {
+  if (!h || i < 0 || i >= (int64_t)h->params.size()) return MVAE_E_INVALID;
+  const ParamInfo& p = h->params[i];
+  if (name && name_cap > 0) { strncpy(name, p.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (shape) for (int k = 0; k < 4; ++k) shape[k] = p.shape[k];
+  if (ndim) *ndim = p.ndim;
+  if (offset) *offset = p.offset;
+  if (reg) *reg = p.reg;
+  return MVAE_OK;
+}
+int64_t mvae_state_count(const mvae_handle* h) { return h ? (int64_t)h->states.size() : -1; }
+int64_t mvae_state_elems(const mvae_handle* h) { return h ? h->S : -1; }
+int mvae_state_info(const mvae_handle* h, int64_t i, char* name, int32_t name_cap, int64_t* elems, int64_t* offset) {
+  if (!h || i < 0 || i >= (int64_t)h->states.size()) return MVAE_E_INVALID;
+  const StateInfo& s = h->states[i];
+  if (name && name_cap > 0) { strncpy(name, s.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (elems) *elems = s.elems;
+  if (offset) *offset = s.offset;
+  return MVAE_OK;
+}
+int64_t mvae_latent_dim(const mvae_handle* h) { return h ? h->Z : -1; }
+int64_t mvae_reduce_elems(const mvae_handle* h) { return h ? h->P + h->S + h->MET : -1; }
+int64_t mvae_metrics_offset(const mvae_handle* h) { return h ? h->P + h->S : -1; }
+int64_t mvae_workspace_bytes(const mvae_handle* h) { return h ? h->ws_floats * 4 : -1; }
+
+int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena, float* accum, float* state,
+              void* workspace, int64_t workspace_bytes) {
+  if (!h) return MVAE_E_INVALID;
+  if (!params || !reduce_arena || !accum || !state || !workspace) return fail(h, MVAE_E_INVALID, "null device pointer");
+  if (workspace_bytes < h->ws_floats * 4)
+    return fail(h, MVAE_E_NOMEM, "workspace too small: %lld < %lld bytes", (long long)workspace_bytes,
+                (long long)(h->ws_floats * 4));
+  if (h->bound) return fail(h, MVAE_E_STATE, "handle already bound");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(h, MVAE_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+  h->device = device;
+  h->dp = params; h->dr = reduce_arena; h->da = accum; h->ds = state; h->ws = static_cast<float*>(workspace);
+  rebase_all(h);
+  e = hipMemcpy(h->d_chunks, h->chunks.data(), h->chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !h->sdescs.empty())
+    e = hipMemcpy(h->d_sdescs, h->sdescs.data(), h->sdescs.size() * sizeof(StateDesc), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail(h, MVAE_E_HIP, "table upload: %s", hipGetErrorString(e));
+  // layer_blocks.gaussian_kernel((3,3),(2,2)) (layer_blocks.py:980-1002, multiscale_vae.py:56-57)
+  double gk[9], sum = 0;
+  for (int a = 0; a < 3; ++a)
+    for (int b2 = 0; b2 < 3; ++b2) {
+      double x = -2.0 + 2.0 * b2, y = -2.0 + 2.0 * a;
+      gk[a * 3 + b2] = std::exp(-(x * x + y * y) / 2.0);
+      sum += gk[a * 3 + b2];
+    }
+  float gf[9];
+  for (int i = 0; i < 9; ++i) gf[i] = (float)(gk[i] / sum);
+  set_gauss_constants(gf);
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(h, MVAE_E_HIP, "bind: %s", hipGetErrorString(e));
+  h->bound = true;
+  return MVAE_OK;
+}
+
+int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
+  if (!h || !io) return MVAE_E_INVALID;
+  if (!h->bound) return fail(h, MVAE_E_STATE, "mvae_bind has not been called");
+  const mvae_config& c = h->cfg;
+  const int B = io->batch, L = c.levels, C = c.input_c;
+  if (B <= 0 || B > c.max_batch) return fail(h, MVAE_E_INVALID, "batch %d outside [1, %d]", B, c.max_batch);
+  if (!io->x) return fail(h, MVAE_E_INVALID, "x is null");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool training = io->training != 0;
+  const float* P = h->dp;
+  const int64_t hwC = (int64_t)c.input_h * c.input_w * C;
+  float* metrics = h->dr + h->P + h->S;
+  (void)hipMemsetAsync(metrics, 0, sizeof(float) * h->MET, s);
+
+  // ---- randomness: injected (parity) or Philox on the device (timed runs)
+  const float* eps = io->eps;
+  if (!eps) { launch_rng_normal(h->eps_buf, (int64_t)B * h->Z, c.sample_std, io->seed, 1u, s); eps = h->eps_buf; }
+  const float *noise = nullptr, *keep = nullptr;
+  if (training) {
+    noise = io->noise; keep = io->keep_mask;
+    if (!noise) { launch_rng_normal(h->noise_buf, hwC * B, 1.0f, io->seed, 2u, s); noise = h->noise_buf; }
+    if (!keep) { launch_rng_keepmask(h->keep_buf, (int64_t)B * C, kDropout, io->seed, 3u, s); keep = h->keep_buf; }
+  }
+  // ---- input transform (multiscale_vae.py:129-160)
+  launch_prep(io->x, noise, keep, h->scales[0].pcur, B, c.input_h, c.input_w, C, c.min_value, c.max_value,
+              1.0f / (c.max_value - c.min_value), 1.0f / (1.0f - kDropout), s);
+  for (int l = 0; l + 1 < L; ++l) {
+    Scale& sc = h->scales[l];
+    launch_blur_split(sc.pcur, sc.band, h->scales[l + 1].pcur, B, sc.H, sc.W, C, s);
+  }
+  // ---- per-scale VAE
+  PreOp none{nullptr, nullptr, nullptr};
+  for (int si = 0; si < L; ++si) {
+    Scale& sc = h->scales[si];
+    ConvGeom g{};
+    g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
+    g.KH = g.KW = 3; g.SH = g.SW = 1; g.PT = g.PL = 1;
+    launch_conv_f(sc.band, P + sc.cb_w, P + sc.cb_b, nullptr, sc.e0, g, none, ACT_ELU, s);
+    const float* x = sc.e0;
+    for (Block& blk : sc.enc) {
+      if (blk.has_conv) {
+        ConvGeom cg = blk.cg; cg.B = B;
+        launch_conv_f(x, P + blk.cw, P + blk.cb, nullptr, blk.cout, cg, none, ACT_NONE, s);
+        x = blk.cout;
+      }
+      mn_forward(h, blk.mn, x, B, training, s);
+      x = blk.mn.out;
+    }
+    launch_gemm_nn(x, P + sc.mu_w, P + sc.mu_b, sc.mu, nullptr, B, (int)sc.K, sc.z, ACT_NONE, s);
+    launch_gemm_nn(x, P + sc.lv_w, P + sc.lv_b, sc.lv, nullptr, B, (int)sc.K, sc.z, ACT_NONE, s);
+    launch_sample_kl(sc.mu, sc.lv, eps, (int)h->Z, sc.z_off, sc.zs, h->losses, 3 + L, 3 + si, B, sc.z, s);
+    if (io->mu) launch_copy_cols(sc.mu, sc.z, 0, io->mu, (int)h->Z, sc.z_off, B, sc.z, s);
+    if (io->log_var) launch_copy_cols(sc.lv, sc.z, 0, io->log_var, (int)h->Z, sc.z_off, B, sc.z, s);
+    if (io->z) launch_copy_cols(sc.zs, sc.z, 0, io->z, (int)h->Z, sc.z_off, B, sc.z, s);
+    decoder_forward(h, sc, B, training, s);
+  }
+  merge_forward(h, B, h->recon, s);
+  launch_loss_fwd(io->x, h->recon, h->losses, 3 + L, L, h->sgn, B, c.input_h, c.input_w, C, s);
+  launch_metrics(h->losses, 3 + L, B, metrics, s);
+  if (io->recon) (void)hipMemcpyAsync(io->recon, h->recon, sizeof(float) * hwC * B, hipMemcpyDeviceToDevice, s);
+  if (io->losses)
+    (void)hipMemcpyAsync(io->losses, h->losses, sizeof(float) * (3 + L) * B, hipMemcpyDeviceToDevice, s);
+  h->last_B = B; h->last_training = training; h->last_x = io->x; h->last_eps = eps;
+  if (training) h->last_train_B = B;
+  return check_launch(h, "mvae_forward");
+}
+
+int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream) {
+  if (!h) return MVAE_E_INVALID;
+  if (!h->bound || h->last_B <= 0 || !h->last_training)
+    return fail(h, MVAE_E_STATE, "mvae_backward needs a preceding training-mode mvae_forward");
+  const mvae_config& c = h->cfg;
+  const int B = h->last_B, L = c.levels, C = c.input_c;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* P = h->dp;
+  float* G = h->dr;
+  PreOp none{nullptr, nullptr, nullptr};
+  (void)hipMemsetAsync(G, 0, sizeof(float) * h->P, s);
+  // ---- loss -> clip/denormalise -> merge
+  launch_loss_bwd(h->last_x, h->recon, h->scales[0].merged, h->sgn, h->scales[0].dy, B, c.input_h, c.input_w, C,
+                  c.min_value, c.max_value, r_factor / (float)B, s);
+  for (int i = 0; i + 1 < L; ++i)
+    launch_upsample_bwd(h->scales[i].dy, h->scales[i + 1].dy, B, h->scales[i + 1].H, h->scales[i + 1].W, C, s);
+  for (int si = 0; si < L; ++si) {
+    Scale& sc = h->scales[si];
+    for (int k = 0; k < 4; ++k) sc.scratch_used[k] = false;
+    const int64_t M = (int64_t)B * sc.H * sc.W;
+    // ---- output conv + decoder BatchNorm
+    const float* xbn = sc.dec.back().mn.out;
+    ConvGeom go = geom1x1(B, sc.H, sc.W, sc.dc, C);
+    PreOp bn{nullptr, sc.bn_scale, sc.bn_shift};
+    launch_conv_wgrad(xbn, sc.dy, G + sc.out_w, go, bn, s);
+    launch_colsum(sc.dy, G + sc.out_b, M, C, s);
+    float* d = acquire(sc);
+    launch_conv_t(sc.dy, P + sc.out_w, nullptr, nullptr, d, go, s);
+    (void)hipMemsetAsync(sc.bn_sum_d, 0, sizeof(float) * sc.dc, s);
+    (void)hipMemsetAsync(sc.bn_sum_dx, 0, sizeof(float) * sc.dc, s);
+    launch_bn_bwd_reduce(d, xbn, sc.bn_mean, sc.bn_invstd, sc.bn_sum_d, sc.bn_sum_dx, M, sc.dc, s);
+    launch_bn2d_bwd_apply(d, xbn, sc.bn_mean, sc.bn_invstd, P + sc.bn_g, sc.bn_sum_d, sc.bn_sum_dx, G + sc.bn_g,
+                          G + sc.bn_b, M, sc.dc, s);
+    // ---- decoder blocks, last to first
+    for (int i = (int)sc.dec.size() - 1; i >= 0; --i) {
+      Block& blk = sc.dec[i];
+      const float* prev = i == 0 ? sc.d0 : sc.dec[i - 1].mn.out;
+      const float* xin = blk.has_conv ? blk.cout : prev;
+      d = mn_backward(h, sc, blk.mn, xin, d, B, s);
+      if (blk.has_conv) {     // Conv2DTranspose: big = its output (d), small = its input (prev)
+        ConvGeom g = blk.cg; g.B = B;
+        launch_conv_wgrad(d, prev, G + blk.cw, g, none, s);
+        launch_colsum(d, G + blk.cb, (int64_t)B * g.IH * g.IW, g.CI, s);
+        float* n = acquire(sc);
+        launch_conv_f(d, P + blk.cw, nullptr, nullptr, n, g, none, ACT_NONE, s);
+        release(sc, d);
+        d = n;
+      }
+    }
+    // ---- decoder Dense, sampling + KL, encoder Dense heads
+    launch_gemm_tn(sc.zs, d, G + sc.dd_w, G + sc.dd_b, B, sc.z, (int)sc.K, nullptr, nullptr, nullptr, s);
+    launch_gemm_nt(d, P + sc.dd_w, sc.dz, B, sc.z, (int)sc.K, nullptr, 0, s);
+    launch_sample_kl_bwd(sc.dz, sc.mu, sc.lv, h->last_eps, (int)h->Z, sc.z_off, sc.dmu, sc.dlv,
+                         kl_factor / (float)B, B, sc.z, s);
+    const float* flat = sc.enc.back().mn.out;
+    launch_gemm_tn(flat, sc.dmu, G + sc.mu_w, G + sc.mu_b, B, (int)sc.K, sc.z, nullptr, nullptr, nullptr, s);
+    launch_gemm_tn(flat, sc.dlv, G + sc.lv_w, G + sc.lv_b, B, (int)sc.K, sc.z, nullptr, nullptr, nullptr, s);
+    launch_gemm_nt(sc.dmu, P + sc.mu_w, d, B, (int)sc.K, sc.z, nullptr, 0, s);
+    launch_gemm_nt(sc.dlv, P + sc.lv_w, d, B, (int)sc.K, sc.z, nullptr, 1, s);
+    // ---- encoder blocks, last to first
+    for (int i = (int)sc.enc.size() - 1; i >= 0; --i) {
+      Block& blk = sc.enc[i];
+      const float* prev = i == 0 ? sc.e0 : sc.enc[i - 1].mn.out;
+      const float* xin = blk.has_conv ? blk.cout : prev;
+      d = mn_backward(h, sc, blk.mn, xin, d, B, s);
+      if (blk.has_conv) {     // Conv2D: big = its input (prev), small = its output (d)
+        ConvGeom g = blk.cg; g.B = B;
+        launch_conv_wgrad(prev, d, G + blk.cw, g, none, s);
+        launch_colsum(d, G + blk.cb, (int64_t)B * g.OH * g.OW, g.CO, s);
+        float* n = acquire(sc);
+        launch_conv_t(d, P + blk.cw, nullptr, nullptr, n, g, s);
+        release(sc, d);
+        d = n;
+      }
+    }
+    // ---- conv_base (ELU): weight gradients only, its input is data
+    launch_elu_bwd(d, sc.e0, M * kConvBaseFilters, s);
+    ConvGeom g{};
+    g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
+    g.KH = g.KW = 3; g.SH = g.SW = 1; g.PT = g.PL = 1;
+    launch_conv_wgrad(sc.band, d, G + sc.cb_w, g, none, s);
+    launch_colsum(d, G + sc.cb_b, M, kConvBaseFilters, s);
+    release(sc, d);
+  }
+  return check_launch(h, "mvae_backward");
+}
+
+int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_scale, void* stream) {
+  if (!h) return MVAE_E_INVALID;
+  if (!h->bound) return fail(h, MVAE_E_STATE, "mvae_bind has not been called");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  (void)hipMemsetAsync(h->d_norms, 0, sizeof(float) * h->params.size(), s);
+  launch_opt_prepare(h->dp, h->dr, h->d_chunks, (int)h->chunks.size(), h->d_norms, grad_scale, s);
+  launch_opt_apply(h->dp, h->dr, h->da, h->d_chunks, (int)h->chunks.size(), h->d_norms, lr, clip_norm, s);
+  // BN moving statistics from the (all-reduced, hence grad_scale) batch statistics
+  launch_state_update(h->ds, h->dr + h->P, h->d_sdescs, (int)h->sdescs.size(), grad_scale, h->last_train_B, s);
+  return check_launch(h, "mvae_apply_adagrad");
+}
+
+int mvae_train_step(mvae_handle* h, const mvae_step_io* io, float r_factor, float kl_factor, float lr,
+                    float clip_norm, void* stream) {
+  if (!io || !io->training) return h ? fail(h, MVAE_E_INVALID, "mvae_train_step needs io->training = 1") : MVAE_E_INVALID;
+  int rc = mvae_forward(h, io, stream);
+  if (rc != MVAE_OK) return rc;
+  rc = mvae_backward(h, r_factor, kl_factor, stream);
+  if (rc != MVAE_OK) return rc;
+  return mvae_apply_adagrad(h, lr, clip_norm, 1.0f, stream);
+}
+
+int mvae_reg_loss(mvae_handle* h, float* out_dev, void* stream) {
+  if (!h || !out_dev) return MVAE_E_INVALID;
+  if (!h->bound) return fail(h, MVAE_E_STATE, "mvae_bind has not been called");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  (void)hipMemsetAsync(out_dev, 0, sizeof(float), s);
+  launch_reg_loss(h->dp, h->d_chunks, (int)h->chunks.size(), out_dev, s);
+  return check_launch(h, "mvae_reg_loss");
+}
+
+int mvae_decode(mvae_handle* h, const float* z, int32_t batch, float* recon, void* stream) {
+  if (!h || !z || !recon) return MVAE_E_INVALID;
+  if (!h->bound) return fail(h, MVAE_E_STATE, "mvae_bind has not been called");
+  const mvae_config& c = h->cfg;
+  if (batch <= 0 || batch > c.max_batch) return fail(h, MVAE_E_INVALID, "batch %d outside [1, %d]", batch, c.max_batch);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (Scale& sc : h->scales) {
+    launch_copy_cols(z, (int)h->Z, sc.z_off, sc.zs, sc.z, 0, batch, sc.z, s);
+    decoder_forward(h, sc, batch, false, s);
+  }
+  merge_forward(h, batch, recon, s);
+  h->last_B = 0;   // activations no longer belong to a training forward
+  return check_launch(h, "mvae_decode");
+}
+
+int mvae_tensor_lookup(const mvae_handle* h, const char* name, float** ptr, int64_t* elems_per_image) {
+  if (!h || !name) return MVAE_E_INVALID;
+  auto it = h->tensors.find(name);
+  if (it == h->tensors.end()) return MVAE_E_INVALID;
+  if (ptr) *ptr = h->bound ? h->ws + it->second.first : nullptr;
+  if (elems_per_image) *elems_per_image = it->second.second;
+  return MVAE_OK;
+}
+
+}  // extern "C"

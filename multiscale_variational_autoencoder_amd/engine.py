@@ -1,0 +1,222 @@
+"""
+Device engine: owns one mvae_handle (C ABI, include/mvae_hip.h) plus the torch-allocated device memory it is
+bound to.  torch is plumbing only (device memory, the HIP stream, torch.distributed/RCCL); every kernel on
+the path is in libmvae_hip.so.  Replaces what Keras/TensorFlow did for the reference when
+mvae/multiscale_vae.py:550-557 called `self._model_trainable.fit`.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _abi
+
+
+class MvaeError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    def __init__(self, input_dims, z_dims, encoder, decoder, min_value, max_value, sample_std, max_batch):
+        self.lib = _abi.load_library()
+        self.cfg = _abi.make_config(input_dims, z_dims, encoder, decoder, min_value, max_value, sample_std, max_batch)
+        self.input_dims = tuple(int(v) for v in input_dims)
+        self.levels = len(z_dims)
+        self.max_batch = int(max_batch)
+        h = C.c_void_p()
+        rc = self.lib.mvae_create(C.byref(self.cfg), C.byref(h))
+        if rc != _abi.MVAE_OK:
+            msg = self.lib.mvae_last_error(None).decode()
+            raise ValueError(msg) if rc == _abi.MVAE_E_INVALID else MvaeError(msg)
+        self.h = h
+        self.bound = False
+        self._read_tables()
+
+    # ------------------------------------------------------------------ tables
+    def _read_tables(self):
+        lib, h = self.lib, self.h
+        self.P = lib.mvae_param_elems(h)
+        self.S = lib.mvae_state_elems(h)
+        self.Z = lib.mvae_latent_dim(h)
+        self.R = lib.mvae_reduce_elems(h)
+        self.metrics_off = lib.mvae_metrics_offset(h)
+        self.ws_bytes = lib.mvae_workspace_bytes(h)
+        self.param_table = OrderedDict()
+        name = C.create_string_buffer(_abi.MVAE_NAME_CAP)
+        shape = (C.c_int64 * 4)()
+        ndim, reg, off = C.c_int32(), C.c_int32(), C.c_int64()
+        for i in range(lib.mvae_param_count(h)):
+            lib.mvae_param_info(h, i, name, _abi.MVAE_NAME_CAP, shape, C.byref(ndim), C.byref(off), C.byref(reg))
+            self.param_table[name.value.decode()] = dict(
+                shape=tuple(int(shape[k]) for k in range(ndim.value)), offset=int(off.value),
+                reg=_abi.REG_NAMES[reg.value])
+        self.state_table = OrderedDict()
+        elems = C.c_int64()
+        for i in range(lib.mvae_state_count(h)):
+            lib.mvae_state_info(h, i, name, _abi.MVAE_NAME_CAP, C.byref(elems), C.byref(off))
+            self.state_table[name.value.decode()] = dict(shape=(int(elems.value),), offset=int(off.value))
+
+    def _check(self, rc):
+        if rc != _abi.MVAE_OK:
+            msg = self.lib.mvae_last_error(self.h).decode()
+            raise ValueError(msg) if rc == _abi.MVAE_E_INVALID else MvaeError("mvae error %d: %s" % (rc, msg))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mvae_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ device memory
+    def bind(self, device_index=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise MvaeError("no HIP device visible: the MI355X kernels are the only compute path (no CPU fallback)")
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        self.torch = torch
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(self.P, **f32)
+        self.reduce = torch.zeros(self.R, **f32)          # [grads | BN batch statistics | metrics]
+        self.accum = torch.full((self.P,), 0.1, **f32)    # keras Adagrad initial_accumulator_value
+        self.state = torch.zeros(max(self.S, 1), **f32)
+        self.workspace = torch.zeros(self.ws_bytes // 4 + 64, **f32)
+        st = np.zeros(max(self.S, 1), np.float32)
+        for k, v in self.state_table.items():              # moving_mean = 0, moving_variance = 1
+            if k.endswith(".var"):
+                st[v["offset"]:v["offset"] + v["shape"][0]] = 1.0
+        self.state.copy_(torch.from_numpy(st))
+        self._check(self.lib.mvae_bind(self.h, device_index, _ptr(self.params), _ptr(self.reduce), _ptr(self.accum),
+                                       _ptr(self.state), _ptr(self.workspace), self.workspace.numel() * 4))
+        self.bound = True
+        return self
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _pack(self, table, values, total):
+        flat = np.zeros(total, np.float32)
+        for k, meta in table.items():
+            a = np.asarray(values[k], np.float32)
+            if tuple(a.shape) != tuple(meta["shape"]):
+                raise ValueError("tensor %s has shape %s, expected %s" % (k, a.shape, meta["shape"]))
+            flat[meta["offset"]:meta["offset"] + a.size] = a.ravel()
+        return flat
+
+    def _unpack(self, table, flat):
+        out = OrderedDict()
+        for k, meta in table.items():
+            n = int(np.prod(meta["shape"]))
+            out[k] = flat[meta["offset"]:meta["offset"] + n].reshape(meta["shape"]).copy()
+        return out
+
+    def set_params(self, values):
+        self.params.copy_(self.torch.from_numpy(self._pack(self.param_table, values, self.P)))
+
+    def get_params(self):
+        return self._unpack(self.param_table, self.params.cpu().numpy())
+
+    def set_accum(self, values):
+        self.accum.copy_(self.torch.from_numpy(self._pack(self.param_table, values, self.P)))
+
+    def get_accum(self):
+        return self._unpack(self.param_table, self.accum.cpu().numpy())
+
+    def get_grads(self):
+        return self._unpack(self.param_table, self.reduce[:self.P].cpu().numpy())
+
+    def set_state(self, values):
+        self.state.copy_(self.torch.from_numpy(self._pack(self.state_table, values, max(self.S, 1))))
+
+    def get_state(self):
+        return self._unpack(self.state_table, self.state.cpu().numpy())
+
+    def to_device(self, a):
+        t = self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
+        return t.to(self.device, non_blocking=False)
+
+    # ------------------------------------------------------------------ the hot path
+    def forward(self, x, training, eps=None, noise=None, keep_mask=None, seed=0, outputs=("recon",)):
+        """x: contiguous float32 CUDA tensor [B,H,W,C].  Returns the requested device tensors."""
+        torch = self.torch
+        B = int(x.shape[0])
+        if tuple(x.shape[1:]) != self.input_dims or x.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError("x must be a contiguous float32 tensor [B,%d,%d,%d]" % self.input_dims)
+        io = _abi.MvaeStepIO()
+        io.x, io.batch, io.training, io.seed = x.data_ptr(), B, 1 if training else 0, int(seed) & (2 ** 64 - 1)
+        io.eps = eps.data_ptr() if eps is not None else None
+        io.noise = noise.data_ptr() if noise is not None else None
+        io.keep_mask = keep_mask.data_ptr() if keep_mask is not None else None
+        out = {}
+        f32 = dict(dtype=torch.float32, device=self.device)
+        if "recon" in outputs:
+            out["recon"] = torch.empty((B,) + self.input_dims, **f32); io.recon = out["recon"].data_ptr()
+        for k in ("mu", "log_var", "z"):
+            if k in outputs:
+                out[k] = torch.empty((B, self.Z), **f32); setattr(io, k, out[k].data_ptr())
+        if "losses" in outputs:
+            out["losses"] = torch.empty((B, 3 + self.levels), **f32); io.losses = out["losses"].data_ptr()
+        self._keep = (x, eps, noise, keep_mask)       # backward reads x / eps again
+        self._check(self.lib.mvae_forward(self.h, C.byref(io), self._stream()))
+        return out
+
+    def backward(self, r_factor, kl_factor):
+        self._check(self.lib.mvae_backward(self.h, float(r_factor), float(kl_factor), self._stream()))
+
+    def apply(self, lr, clip_norm, grad_scale=1.0):
+        self._check(self.lib.mvae_apply_adagrad(self.h, float(lr), float(clip_norm if clip_norm else 0.0),
+                                                float(grad_scale), self._stream()))
+
+    def train_step(self, x, lr, r_factor, kl_factor, clip_norm, eps=None, noise=None, keep_mask=None, seed=0):
+        """forward + backward (+ one RCCL all-reduce of the reduce arena when torch.distributed is up) + Adagrad."""
+        self.forward(x, True, eps, noise, keep_mask, seed, outputs=())
+        self.backward(r_factor, kl_factor)
+        scale = 1.0
+        dist = self.torch.distributed
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.reduce)                  # grads | BN batch statistics | metrics, one message
+            scale = 1.0 / dist.get_world_size()
+        self.apply(lr, clip_norm, scale)
+
+    def metrics(self):
+        """{count, vae_r_loss, r_exp, vae_kl_loss, kl_scale_i} means of the last forward (synchronises)."""
+        m = self.reduce[self.metrics_off:self.metrics_off + 4 + self.levels].cpu().numpy().astype(np.float64)
+        n = max(m[0], 1.0)
+        out = dict(count=m[0], vae_r_loss=m[1] / n, r_exp=m[2] / n, vae_kl_loss=m[3] / n)
+        for s in range(self.levels):
+            out["kl_scale_%d" % s] = m[4 + s] / n
+        return out
+
+    def reg_loss(self):
+        t = self.torch.zeros(1, dtype=self.torch.float32, device=self.device)
+        self._check(self.lib.mvae_reg_loss(self.h, _ptr(t), self._stream()))
+        return float(t.item())
+
+    def decode(self, z):
+        torch = self.torch
+        B = int(z.shape[0])
+        if z.shape[1] != self.Z or z.dtype != torch.float32 or not z.is_contiguous():
+            raise ValueError("z must be a contiguous float32 tensor [B,%d]" % self.Z)
+        out = torch.empty((B,) + self.input_dims, dtype=torch.float32, device=self.device)
+        self._check(self.lib.mvae_decode(self.h, _ptr(z), B, _ptr(out), self._stream()))
+        return out
+
+    def tensor(self, name, batch):
+        """Debug/parity view of a saved intermediate of the last forward: [batch, elems_per_image]."""
+        p, n = C.c_void_p(), C.c_int64()
+        rc = self.lib.mvae_tensor_lookup(self.h, name.encode(), C.byref(p), C.byref(n))
+        if rc != _abi.MVAE_OK:
+            raise KeyError(name)
+        off = (p.value - self.workspace.data_ptr()) // 4
+        return self.workspace[off:off + batch * n.value].view(batch, n.value)

@@ -1,0 +1,466 @@
+"""
+CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+A CPU restatement (torch-CPU, float64 by default, autograd for gradients) of the
+one hot path this repository accelerates: the multiscale VAE train step of
+`mvae.MultiscaleVAE` (reference: /root/reference/mvae/multiscale_vae.py and
+/root/reference/mvae/layer_blocks.py).  Only `tests/`, `__graft_entry__.smoke()`
+and the `cpu_baseline` leg of `bench.py` may import this module; the shipped
+package never does.
+
+PARITY STATUS: **parity unpinned** for the ELBO, gradients and optimiser.
+The reference cannot be imported here (Keras 2.4.3 / tensorflow-gpu 2.3.1 are
+not installed, `import mvae` itself fails at mvae/callbacks.py:10) and its own
+tests (tests/test_layer_blocks.py:9-39) pin only the Gaussian-blur constants
+and zero padding, which `tests/test_oracle_golden.py` replays against
+`gaussian_kernel` / `gaussian_blur` below.  Everything else follows the
+documented Keras 2.4.3 / TF 2.3.1 operator semantics, restated by hand, and is
+cross-checked by an independent loop-level numpy restatement in
+`oracle/np_ops.py`.
+
+Every function cites the reference lines it restates.  Tensors cross this API
+as NHWC numpy/torch arrays exactly like the reference's Keras tensors.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+CONV_BASE_FILTERS = 32          # multiscale_vae.py:50
+TRAINING_DROPOUT = 0.1          # multiscale_vae.py:58
+GAUSSIAN_KERNEL = (3, 3)        # multiscale_vae.py:56
+GAUSSIAN_NSIG = (2, 2)          # multiscale_vae.py:57
+L1_COEF = 0.01                  # keras.regularizers.l1() default, "l1" string
+L2_COEF = 0.01                  # keras.regularizers.l2() default, "l2" string
+SE_BN_MOMENTUM, SE_BN_EPS = 0.99, 1e-3      # keras BatchNormalization defaults, layer_blocks.py:448
+DEC_BN_MOMENTUM, DEC_BN_EPS = 0.999, 1e-4   # multiscale_vae.py:420-421
+ADAGRAD_INIT_ACC, ADAGRAD_EPS = 0.1, 1e-7   # keras.optimizers.Adagrad (TF 2.3) defaults
+
+
+# ----------------------------------------------------------------------------------------------
+# configuration (multiscale_vae.py:12-69)
+# ----------------------------------------------------------------------------------------------
+class OracleConfig:
+    def __init__(self, input_dims, z_dims, encoder=None, decoder=None,
+                 min_value=0.0, max_value=255.0, sample_std=0.01):
+        if encoder is None:
+            encoder = {"filters": [32], "kernel_size": [(3, 3)], "strides": [(1, 1)]}
+        if decoder is None:                                   # multiscale_vae.py:40-45
+            decoder = {k: list(encoder[k])[::-1] for k in ("filters", "strides", "kernel_size")}
+        self.input_dims = tuple(int(v) for v in input_dims)
+        self.z_dims = [int(z) for z in z_dims]
+        self.levels = len(self.z_dims)                        # multiscale_vae.py:46
+        self.encoder = {k: [tuple(v) if isinstance(v, (list, tuple)) else int(v) for v in encoder[k]]
+                        for k in ("filters", "kernel_size", "strides")}
+        self.decoder = {k: [tuple(v) if isinstance(v, (list, tuple)) else int(v) for v in decoder[k]]
+                        for k in ("filters", "kernel_size", "strides")}
+        self.min_value = float(min_value)
+        self.max_value = float(max_value)
+        self.sample_std = float(sample_std)
+        self.noise_std = 1.0 / (self.max_value - self.min_value)   # multiscale_vae.py:59
+
+    def scales(self):
+        """compute_scales, multiscale_vae.py:111-127: int(n/2) per level on H and W."""
+        out = [self.input_dims]
+        for _ in range(1, self.levels):
+            h, w, c = out[-1]
+            out.append((int(h / 2), int(w / 2), c))
+        return out
+
+
+def same_pads(n_in, k, s):
+    """TF 'SAME' padding: out=ceil(n/s); total=max((out-1)s+k-n,0); extra goes after."""
+    out = -(-n_in // s)
+    total = max((out - 1) * s + k - n_in, 0)
+    return out, total // 2, total - total // 2
+
+
+def _block_plan(cfg, which, c_in, h, w):
+    """basic_block, layer_blocks.py:934-972: per list entry an optional conv and one MNv3 block."""
+    d = cfg.encoder if which == "enc" else cfg.decoder
+    plan = []
+    prev = c_in
+    for i, (f, k, s) in enumerate(zip(d["filters"], d["kernel_size"], d["strides"])):
+        conv = None
+        if s[0] != 1 or s[1] != 1 or f != prev:               # layer_blocks.py:946-947
+            if which == "enc":
+                oh, ow = same_pads(h, k[0], s[0])[0], same_pads(w, k[1], s[1])[0]
+            else:
+                oh, ow = h * s[0], w * s[1]
+            conv = dict(k=k, s=s, cin=prev, cout=f, ih=h, iw=w, oh=oh, ow=ow)
+            h, w = oh, ow
+        plan.append(dict(i=i, conv=conv, c=f, h=h, w=w))
+        prev = f
+    return plan, prev, h, w
+
+
+def param_table(cfg):
+    """
+    Canonical (name -> (shape, reg)) table of trainable tensors, in arena order, plus the
+    non-trainable state table (BatchNorm moving statistics).  Mirrors the layers created by
+    _build_encoder (multiscale_vae.py:319-385), basic_block / mobilenetV3_block /
+    squeeze_excite_block (layer_blocks.py:893-974, 556-648, 418-462) and _build_decoder
+    (multiscale_vae.py:389-433).  reg: "l1" / "l2" / None (biases and BN carry none).
+    """
+    P, S = OrderedDict(), OrderedDict()
+    C = cfg.input_dims[2]
+
+    def mn(prefix, c):
+        P[prefix + ".conv0.w"] = ((1, 1, c, c), "l1"); P[prefix + ".conv0.b"] = ((c,), None)
+        P[prefix + ".dw.w"] = ((3, 3, c, 1), "l1");    P[prefix + ".dw.b"] = ((c,), None)
+        P[prefix + ".se.d0.w"] = ((c, c), "l1");       P[prefix + ".se.d0.b"] = ((c,), None)
+        P[prefix + ".se.bn.gamma"] = ((c,), None);     P[prefix + ".se.bn.beta"] = ((c,), None)
+        S[prefix + ".se.bn.mean"] = (c,);              S[prefix + ".se.bn.var"] = (c,)
+        P[prefix + ".se.d1.w"] = ((c, c), "l1");       P[prefix + ".se.d1.b"] = ((c,), None)
+        P[prefix + ".conv2.w"] = ((1, 1, c, c), "l1"); P[prefix + ".conv2.b"] = ((c,), None)
+
+    for s, (H, W, _) in enumerate(cfg.scales()):
+        e = "enc%d" % s
+        P[e + ".conv_base.w"] = ((3, 3, C, CONV_BASE_FILTERS), "l2")
+        P[e + ".conv_base.b"] = ((CONV_BASE_FILTERS,), None)
+        plan, c_last, h, w = _block_plan(cfg, "enc", CONV_BASE_FILTERS, H, W)
+        for b in plan:
+            if b["conv"] is not None:
+                cv = b["conv"]
+                P["%s.b%d.conv.w" % (e, b["i"])] = ((cv["k"][0], cv["k"][1], cv["cin"], cv["cout"]), "l1")
+                P["%s.b%d.conv.b" % (e, b["i"])] = ((cv["cout"],), None)
+            mn("%s.b%d.mn" % (e, b["i"]), b["c"])
+        K = h * w * c_last
+        z = cfg.z_dims[s]
+        P[e + ".mu.w"] = ((K, z), "l2");      P[e + ".mu.b"] = ((z,), None)
+        P[e + ".log_var.w"] = ((K, z), "l2"); P[e + ".log_var.b"] = ((z,), None)
+        d = "dec%d" % s
+        P[d + ".dense.w"] = ((z, K), "l2");   P[d + ".dense.b"] = ((K,), None)
+        dplan, dc_last, dh, dw = _block_plan(cfg, "dec", c_last, h, w)
+        for b in dplan:
+            if b["conv"] is not None:
+                cv = b["conv"]
+                # Conv2DTranspose kernel layout (kh, kw, out, in)
+                P["%s.b%d.convT.w" % (d, b["i"])] = ((cv["k"][0], cv["k"][1], cv["cout"], cv["cin"]), "l1")
+                P["%s.b%d.convT.b" % (d, b["i"])] = ((cv["cout"],), None)
+            mn("%s.b%d.mn" % (d, b["i"]), b["c"])
+        if (dh, dw) != (H, W):
+            raise ValueError("decoder of scale %d produces %dx%d, scale is %dx%d" % (s, dh, dw, H, W))
+        P[d + ".bn.gamma"] = ((dc_last,), None); P[d + ".bn.beta"] = ((dc_last,), None)
+        S[d + ".bn.mean"] = (dc_last,);          S[d + ".bn.var"] = (dc_last,)
+        P[d + ".out.w"] = ((1, 1, dc_last, C), "l2"); P[d + ".out.b"] = ((C,), None)
+    return P, S
+
+
+# ----------------------------------------------------------------------------------------------
+# primitive ops (Keras 2.4.3 / TF 2.3.1 semantics), NCHW inside, NHWC at the API
+# ----------------------------------------------------------------------------------------------
+def gaussian_kernel(size, nsig):
+    """layer_blocks.py:980-1002 restated."""
+    k1 = [np.linspace(-abs(nsig[i]), abs(nsig[i]), size[i], endpoint=True) for i in range(2)]
+    x, y = np.meshgrid(k1[0], k1[1])
+    g = np.exp(-((np.sqrt(x * x + y * y)) ** 2 / 2.0))
+    return g / g.sum()
+
+
+def conv2d_same(x, w_hwio, b, stride):
+    """keras.layers.Conv2D(padding='same'): cross-correlation, kernel HWIO, asymmetric SAME pad."""
+    kh, kw = w_hwio.shape[0], w_hwio.shape[1]
+    _, pt, pb = same_pads(x.shape[2], kh, stride[0])
+    _, pl, pr = same_pads(x.shape[3], kw, stride[1])
+    y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w_hwio.permute(3, 2, 0, 1), b, stride=stride)
+    return y
+
+
+def conv2d_transpose_same(x, w_hwoi, b, stride):
+    """keras.layers.Conv2DTranspose(padding='same'), kernel (kh,kw,out,in): the exact adjoint of the
+    SAME conv that maps size n*s -> n (layer_blocks.py:950-951)."""
+    kh, kw = w_hwoi.shape[0], w_hwoi.shape[1]
+    n_h, n_w = x.shape[2] * stride[0], x.shape[3] * stride[1]
+    full = F.conv_transpose2d(x, w_hwoi.permute(3, 2, 0, 1), None, stride=stride)
+    _, pt, _ = same_pads(n_h, kh, stride[0])
+    _, pl, _ = same_pads(n_w, kw, stride[1])
+    need_h, need_w = pt + n_h - full.shape[2], pl + n_w - full.shape[3]
+    if need_h > 0 or need_w > 0:
+        full = F.pad(full, (0, max(need_w, 0), 0, max(need_h, 0)))
+    y = full[:, :, pt:pt + n_h, pl:pl + n_w]
+    if b is not None:
+        y = y + b.view(1, -1, 1, 1)
+    return y
+
+
+def depthwise3x3_same(x, w_hwc1, b):
+    """keras.layers.DepthwiseConv2D(3x3, stride 1, 'same'), kernel (kh,kw,C,1)."""
+    c = x.shape[1]
+    w = w_hwc1.permute(2, 3, 0, 1)           # (C,1,kh,kw)
+    return F.conv2d(F.pad(x, (1, 1, 1, 1)), w, b, groups=c)
+
+
+def gaussian_blur(x):
+    """gaussian_filter_block, layer_blocks.py:1008-1050 with xy_max=(2,2) (multiscale_vae.py:301-305)."""
+    c = x.shape[1]
+    g = torch.as_tensor(gaussian_kernel(GAUSSIAN_KERNEL, GAUSSIAN_NSIG), dtype=x.dtype)
+    w = g.view(1, 1, 3, 3).repeat(c, 1, 1, 1)
+    return F.conv2d(F.pad(x, (1, 1, 1, 1)), w, None, groups=c)
+
+
+def hard_sigmoid(x):
+    """Keras <= 2.x hard_sigmoid: clip(0.2 x + 0.5, 0, 1)."""
+    return torch.clamp(0.2 * x + 0.5, 0.0, 1.0)
+
+
+def batchnorm_train(x, gamma, beta, eps, dims, group):
+    """training-mode BN: batch mean, biased variance; optional per-replica groups of `group` samples."""
+    B = x.shape[0]
+    if group is None or group >= B:
+        group = B
+    outs, means, vars_ = [], [], []
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    for g0 in range(0, B, group):
+        xg = x[g0:g0 + group]
+        m = xg.mean(dim=dims, keepdim=True)
+        v = ((xg - m) ** 2).mean(dim=dims, keepdim=True)
+        outs.append((xg - m) / torch.sqrt(v + eps) * gamma.view(shape) + beta.view(shape))
+        means.append(m.reshape(-1)); vars_.append(v.reshape(-1))
+    return torch.cat(outs, 0), torch.stack(means).mean(0), torch.stack(vars_).mean(0)
+
+
+def batchnorm_infer(x, gamma, beta, mean, var, eps):
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    return (x - mean.view(shape)) / torch.sqrt(var.view(shape) + eps) * gamma.view(shape) + beta.view(shape)
+
+
+# ----------------------------------------------------------------------------------------------
+# the model
+# ----------------------------------------------------------------------------------------------
+class Oracle:
+    def __init__(self, cfg, dtype=torch.float64):
+        self.cfg = cfg
+        self.dtype = dtype
+        self.ptab, self.stab = param_table(cfg)
+
+    # -- helpers
+    def _t(self, a):
+        return torch.as_tensor(np.asarray(a), dtype=self.dtype)
+
+    def tensors(self, params, requires_grad=False):
+        out = OrderedDict()
+        for k in self.ptab:
+            t = self._t(params[k]).clone()
+            assert tuple(t.shape) == tuple(self.ptab[k][0]), (k, t.shape, self.ptab[k][0])
+            t.requires_grad_(requires_grad)
+            out[k] = t
+        return out
+
+    def init_state(self):
+        st = OrderedDict()
+        for k, shp in self.stab.items():
+            st[k] = np.zeros(shp, np.float64) if k.endswith(".mean") else np.ones(shp, np.float64)
+        return st
+
+    # -- input transform (multiscale_vae.py:129-160, 292-315)
+    def pyramid(self, x_nhwc, noise=None, mask=None):
+        cfg = self.cfg
+        x = self._t(x_nhwc).permute(0, 3, 1, 2)
+        v0, v1 = cfg.min_value, cfg.max_value
+        cur = 2.0 * (x - v0) / (v1 - v0) - 1.0                 # normalize, :79-84
+        if noise is not None:                                  # GaussianNoise, :139-142 (training only)
+            cur = cur + self._t(noise).permute(0, 3, 1, 2) * cfg.noise_std
+        if mask is not None:                                   # SpatialDropout2D(0.1), :144-147
+            cur = cur * self._t(mask).view(mask.shape[0], -1, 1, 1) / (1.0 - TRAINING_DROPOUT)
+        bands = []
+        for i in range(cfg.levels):
+            if i == cfg.levels - 1:
+                bands.append(cur)
+            else:
+                f0 = gaussian_blur(cur)
+                bands.append(cur - f0)                         # Subtract, :314
+                cur = f0[:, :, ::2, ::2]                       # MaxPool2D(1, stride 2), :308-311
+        return bands
+
+    # -- MobileNetV3 block (layer_blocks.py:556-648 + 418-462)
+    def mnv3(self, a, T, p, st, training, group, new_state, inter):
+        t0 = F.relu(conv2d_same(a, T[p + ".conv0.w"], T[p + ".conv0.b"], (1, 1)))
+        t1 = F.relu(depthwise3x3_same(t0, T[p + ".dw.w"], T[p + ".dw.b"]))
+        gap = t1.mean(dim=(2, 3))
+        s0 = F.relu(gap @ T[p + ".se.d0.w"] + T[p + ".se.d0.b"])
+        if training:
+            s1, m, v = batchnorm_train(s0, T[p + ".se.bn.gamma"], T[p + ".se.bn.beta"], SE_BN_EPS, (0,), group)
+            # 2-D (non fused) path: moving variance from the biased batch variance
+            new_state[p + ".se.bn.mean"] = st[p + ".se.bn.mean"] * SE_BN_MOMENTUM + m.detach() * (1 - SE_BN_MOMENTUM)
+            new_state[p + ".se.bn.var"] = st[p + ".se.bn.var"] * SE_BN_MOMENTUM + v.detach() * (1 - SE_BN_MOMENTUM)
+        else:
+            s1 = batchnorm_infer(s0, T[p + ".se.bn.gamma"], T[p + ".se.bn.beta"],
+                                 st[p + ".se.bn.mean"], st[p + ".se.bn.var"], SE_BN_EPS)
+        g = hard_sigmoid(s1 @ T[p + ".se.d1.w"] + T[p + ".se.d1.b"])
+        t2 = t1 * g[:, :, None, None]
+        out = conv2d_same(t2, T[p + ".conv2.w"], T[p + ".conv2.b"], (1, 1)) + a
+        if inter is not None:
+            inter[p + ".t0"], inter[p + ".t1"], inter[p + ".g"], inter[p + ".out"] = t0, t1, g, out
+        return out
+
+    def encode_scale(self, s, band, T, st, eps_s, training, group, new_state, inter):
+        cfg = self.cfg
+        e = "enc%d" % s
+        x = F.elu(conv2d_same(band, T[e + ".conv_base.w"], T[e + ".conv_base.b"], (1, 1)))   # :333-341
+        if inter is not None:
+            inter[e + ".conv_base"] = x
+        plan, _, _, _ = _block_plan(cfg, "enc", CONV_BASE_FILTERS, band.shape[2], band.shape[3])
+        for b in plan:
+            if b["conv"] is not None:
+                x = conv2d_same(x, T["%s.b%d.conv.w" % (e, b["i"])], T["%s.b%d.conv.b" % (e, b["i"])], b["conv"]["s"])
+            x = self.mnv3(x, T, "%s.b%d.mn" % (e, b["i"]), st, training, group, new_state, inter)
+        shape = x.shape[1:]
+        flat = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)                                   # Flatten (H,W,C)
+        mu = flat @ T[e + ".mu.w"] + T[e + ".mu.b"]
+        lv = flat @ T[e + ".log_var.w"] + T[e + ".log_var.b"]
+        z = mu + torch.exp(lv) * eps_s                                                         # :372-378 (exp(log_var)!)
+        return z, mu, lv, shape
+
+    def decode_scale(self, s, z, T, st, shape_chw, training, group, new_state, inter):
+        cfg = self.cfg
+        d = "dec%d" % s
+        c, h, w = shape_chw
+        x = (z @ T[d + ".dense.w"] + T[d + ".dense.b"]).reshape(-1, h, w, c).permute(0, 3, 1, 2)   # :402-408
+        plan, _, _, _ = _block_plan(cfg, "dec", c, h, w)
+        for b in plan:
+            if b["conv"] is not None:
+                x = conv2d_transpose_same(x, T["%s.b%d.convT.w" % (d, b["i"])], T["%s.b%d.convT.b" % (d, b["i"])],
+                                          b["conv"]["s"])
+            x = self.mnv3(x, T, "%s.b%d.mn" % (d, b["i"]), st, training, group, new_state, inter)
+        if training:                                                                              # :420-421
+            xb, m, v = batchnorm_train(x, T[d + ".bn.gamma"], T[d + ".bn.beta"], DEC_BN_EPS, (0, 2, 3), group)
+            n = (x.shape[0] if group is None else min(group, x.shape[0])) * x.shape[2] * x.shape[3]
+            # 4-D fused path: moving variance gets the Bessel-corrected batch variance
+            new_state[d + ".bn.mean"] = st[d + ".bn.mean"] * DEC_BN_MOMENTUM + m.detach() * (1 - DEC_BN_MOMENTUM)
+            new_state[d + ".bn.var"] = st[d + ".bn.var"] * DEC_BN_MOMENTUM + \
+                v.detach() * (n / max(n - 1, 1)) * (1 - DEC_BN_MOMENTUM)
+        else:
+            xb = batchnorm_infer(x, T[d + ".bn.gamma"], T[d + ".bn.beta"], st[d + ".bn.mean"], st[d + ".bn.var"],
+                                 DEC_BN_EPS)
+        y = conv2d_same(xb, T[d + ".out.w"], T[d + ".out.b"], (1, 1))                            # :424-431
+        if inter is not None:
+            inter[d + ".bn_in"], inter[d + ".y"] = x, y
+        return y
+
+    def merge(self, ys):
+        """merge model multiscale_vae.py:204-224 + denormalize :86-94."""
+        cfg = self.cfg
+        x = ys[-1]
+        for i in range(cfg.levels - 2, -1, -1):
+            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) + ys[i]
+        v0, v1 = cfg.min_value, cfg.max_value
+        return torch.clamp((x + 1.0) * (v1 - v0) / 2.0 + v0, v0, v1)
+
+    # -- full forward of the trainable model (multiscale_vae.py:261-288)
+    def forward(self, T, state, x, eps, noise=None, mask=None, training=True, bn_group_size=None, inter=None):
+        cfg = self.cfg
+        st = {k: self._t(v) for k, v in state.items()}
+        new_state = dict(st)
+        bands = self.pyramid(x, noise if training else None, mask if training else None)
+        eps = self._t(eps)
+        zs, mus, lvs, ys = [], [], [], []
+        off = 0
+        for s in range(cfg.levels):
+            z, mu, lv, shape = self.encode_scale(s, bands[s], T, st, eps[:, off:off + cfg.z_dims[s]],
+                                                 training, bn_group_size, new_state, inter)
+            off += cfg.z_dims[s]
+            ys.append(self.decode_scale(s, z, T, st, shape, training, bn_group_size, new_state, inter))
+            zs.append(z); mus.append(mu); lvs.append(lv)
+        recon = self.merge(ys).permute(0, 2, 3, 1)
+        if inter is not None:
+            for s in range(cfg.levels):
+                inter["band%d" % s] = bands[s]
+        return dict(recon=recon, z=torch.cat(zs, 1), mu=torch.cat(mus, 1), log_var=torch.cat(lvs, 1),
+                    new_state=new_state)
+
+    def decode(self, T, state, z):
+        """_model_decoder multiscale_vae.py:247-257 (inference mode)."""
+        cfg = self.cfg
+        st = {k: self._t(v) for k, v in state.items()}
+        z = self._t(z)
+        ys, off = [], 0
+        for s, (H, W, _) in enumerate(cfg.scales()):
+            _, c_last, h, w = _block_plan(cfg, "enc", CONV_BASE_FILTERS, H, W)
+            ys.append(self.decode_scale(s, z[:, off:off + cfg.z_dims[s]], T, st, (c_last, h, w), False, None, {}, None))
+            off += cfg.z_dims[s]
+        return self.merge(ys).permute(0, 2, 3, 1)
+
+    # -- losses (multiscale_vae.py:453-495)
+    def losses(self, x, out):
+        cfg = self.cfg
+        y = self._t(x)
+        yp = out["recon"]
+        H, W = cfg.input_dims[0], cfg.input_dims[1]
+        d0, d1 = int(H / 2), int(W / 2)
+        ap = (y - yp).abs()
+        r = ap.mean(dim=(1, 2, 3))                                                   # vae_r_loss :453-456
+        ch = (y.mean(dim=(1, 2)) - yp.mean(dim=(1, 2))).abs()
+        sl = (slice(None), slice(int(d0 / 2), int(d0 * 3 / 2)), slice(int(d1 / 2), int(d1 * 3 / 2)), slice(None))
+        cc = (y[sl].mean(dim=(1, 2)) - yp[sl].mean(dim=(1, 2))).abs()
+        r_exp = r + (ch.mean(dim=1) + cc.mean(dim=1)) / 2.0                          # :458-481
+        mu, lv = out["mu"], out["log_var"]
+        klt = -0.5 * (1.0 + lv - mu ** 2 - torch.exp(lv))                            # :485-488
+        kl = klt.sum(dim=1)
+        kl_scale, off = [], 0
+        for zdim in cfg.z_dims:
+            kl_scale.append(klt[:, off:off + zdim].sum(dim=1)); off += zdim
+        return dict(r=r, r_exp=r_exp, kl=kl, kl_scale=torch.stack(kl_scale, 1))
+
+    def reg_loss(self, T):
+        """Keras adds 0.01*sum|w| ('l1') or 0.01*sum w^2 ('l2') per regularised kernel."""
+        tot = torch.zeros((), dtype=self.dtype)
+        for k, (_, reg) in self.ptab.items():
+            if reg == "l1":
+                tot = tot + L1_COEF * T[k].abs().sum()
+            elif reg == "l2":
+                tot = tot + L2_COEF * (T[k] ** 2).sum()
+        return tot
+
+    def loss_and_grads(self, params, state, x, eps, noise, mask, r_factor, kl_factor,
+                       bn_group_size=None, inter=None):
+        T = self.tensors(params, requires_grad=True)
+        out = self.forward(T, state, x, eps, noise, mask, True, bn_group_size, inter)
+        L = self.losses(x, out)
+        data = (L["r_exp"] * r_factor + L["kl"] * kl_factor).mean()                  # vae_loss :491-495, batch mean
+        reg = self.reg_loss(T)
+        total = data + reg
+        grads = torch.autograd.grad(total, list(T.values()))
+        G = OrderedDict((k, g.detach().numpy()) for k, g in zip(T.keys(), grads))
+        res = dict(loss=float(total.detach()), data_loss=float(data.detach()), reg_loss=float(reg.detach()),
+                   r=L["r"].detach().numpy(), r_exp=L["r_exp"].detach().numpy(), kl=L["kl"].detach().numpy(),
+                   kl_scale=L["kl_scale"].detach().numpy(),
+                   recon=out["recon"].detach().numpy(), mu=out["mu"].detach().numpy(),
+                   log_var=out["log_var"].detach().numpy(), z=out["z"].detach().numpy(),
+                   new_state=OrderedDict((k, v.numpy()) for k, v in out["new_state"].items()))
+        return res, G
+
+    @staticmethod
+    def adagrad_step(params, accum, grads, lr, clip_norm):
+        """keras.optimizers.Adagrad(lr, clipnorm) multiscale_vae.py:497-499: per-variable
+        tf.clip_by_norm, then a += g^2 ; w -= lr*g/(sqrt(a)+1e-7)."""
+        new_p, new_a = OrderedDict(), OrderedDict()
+        for k in params:
+            g = np.asarray(grads[k], np.float64)
+            if clip_norm is not None:
+                n = math.sqrt(float((g ** 2).sum()))
+                g = g * clip_norm / max(n, clip_norm)
+            a = np.asarray(accum[k], np.float64) + g * g
+            new_a[k] = a
+            new_p[k] = np.asarray(params[k], np.float64) - lr * g / (np.sqrt(a) + ADAGRAD_EPS)
+        return new_p, new_a
+
+    def train_step(self, params, accum, state, x, eps, noise, mask, lr, r_factor, kl_factor, clip_norm,
+                   bn_group_size=None):
+        res, G = self.loss_and_grads(params, state, x, eps, noise, mask, r_factor, kl_factor, bn_group_size)
+        new_p, new_a = self.adagrad_step(params, accum, G, lr, clip_norm)
+        return res, G, new_p, new_a, res["new_state"]
+
+    def predict(self, params, state, x, eps):
+        """model_trainable.predict: no noise/dropout, BN moving statistics, sampling still on."""
+        with torch.no_grad():
+            T = self.tensors(params)
+            out = self.forward(T, state, x, eps, None, None, False)
+        return {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items() if k != "new_state"}
+
+
+def step_decay(initial_lr, decay_factor, step_size, epoch):
+    """schedule.py:17-19."""
+    return initial_lr * (decay_factor ** np.floor(epoch / step_size))

@@ -1,0 +1,119 @@
+"""CPU: pin the oracle against every golden vector the reference's own tests hold for this path
+(/root/reference/tests/test_layer_blocks.py:9-39: Gaussian blur of zeros / ones, :118-131 pyramid shapes) and
+cross-check the torch restatement against the independent numpy loop restatement (oracle/np_ops.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops
+from oracle.mvae_oracle import (Oracle, OracleConfig, conv2d_same, conv2d_transpose_same, gaussian_kernel,
+                                param_table)
+import torch.nn.functional as F
+
+
+def _blur_default(x_nhwc):
+    """gaussian_filter_block with the reference tests' default xy_max=(1,1) (layer_blocks.py:16)."""
+    g = torch.as_tensor(gaussian_kernel((3, 3), (1, 1)))
+    x = torch.as_tensor(x_nhwc).permute(0, 3, 1, 2)
+    c = x.shape[1]
+    w = g.view(1, 1, 3, 3).repeat(c, 1, 1, 1).to(x.dtype)
+    return F.conv2d(F.pad(x, (1, 1, 1, 1)), w, None, groups=c).permute(0, 2, 3, 1).numpy()
+
+
+def test_ref_gaussian_all_zeros():            # tests/test_layer_blocks.py:9-17
+    y = _blur_default(np.zeros((3, 256, 256, 3)))
+    assert y.shape == (3, 256, 256, 3) and np.all(y == 0.0)
+
+
+@pytest.mark.parametrize("shape,hi", [((3, 16, 16, 1), 15), ((3, 9, 9, 7), 8)])   # :20-39
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ref_gaussian_all_ones_interior_exact(shape, hi, dtype):
+    y = _blur_default(np.ones(shape, dtype))
+    assert y.shape == shape
+    assert np.all(y[:, 1:hi, 1:hi, :] == 1.0)
+    # zero SAME padding: borders are attenuated
+    assert abs(y[0, 0, 0, 0] - 0.5269763) < 1e-6 and abs(y[0, 0, 1, 0] - 0.7259313) < 1e-6
+
+
+def test_hot_path_gaussian_constants():       # nsig (2,2)
+    g = gaussian_kernel((3, 3), (2, 2))
+    assert abs(g[1, 1] - 0.6193470306) < 1e-9 and abs(g[0, 1] - 0.0838195058) < 1e-9
+    assert abs(g[0, 0] - 0.0113437366) < 1e-9 and abs(g.sum() - 1.0) < 1e-12
+
+
+def test_ref_pyramid_shapes():                # tests/test_layer_blocks.py:118-131 (shapes of a 3-level split)
+    cfg = OracleConfig((32, 32, 3), [4, 4, 4])
+    x = np.random.default_rng(0).uniform(0, 255, (18, 32, 32, 3))
+    bands = Oracle(cfg).pyramid(x)
+    assert [tuple(b.shape) for b in bands] == [(18, 3, 32, 32), (18, 3, 16, 16), (18, 3, 8, 8)]
+
+
+@pytest.mark.parametrize("H,W,k,s,ci,co", [(8, 8, 5, 2, 3, 4), (7, 9, 3, 2, 2, 3), (6, 6, 1, 1, 4, 4),
+                                            (8, 8, 3, 1, 3, 5), (5, 5, 1, 2, 2, 2), (9, 9, 5, 2, 3, 2)])
+def test_conv_restatements_agree(H, W, k, s, ci, co):
+    rng = np.random.default_rng(0)
+    x, b = rng.standard_normal((2, H, W, ci)), rng.standard_normal(co)
+    w, wt = rng.standard_normal((k, k, ci, co)), rng.standard_normal((k, k, co, ci))
+    xt = torch.tensor(x).permute(0, 3, 1, 2)
+    y = conv2d_same(xt, torch.tensor(w), torch.tensor(b), (s, s)).permute(0, 2, 3, 1).numpy()
+    assert np.abs(y - np_ops.conv2d_same_nhwc(x, w, b, (s, s))).max() < 1e-12
+    y = conv2d_transpose_same(xt, torch.tensor(wt), torch.tensor(b), (s, s)).permute(0, 2, 3, 1).numpy()
+    assert y.shape == (2, H * s, W * s, co)
+    assert np.abs(y - np_ops.conv2d_transpose_same_nhwc(x, wt, b, (s, s))).max() < 1e-12
+
+
+def test_conv_transpose_is_conv_adjoint():
+    """Conv2DTranspose 'same' == VJP of the 'same' conv for input size n*s."""
+    rng = np.random.default_rng(1)
+    for k, s in [(5, 2), (3, 2), (1, 1), (3, 1), (1, 2)]:
+        n = 6
+        w = torch.tensor(rng.standard_normal((k, k, 3, 4)))
+        xb = torch.tensor(rng.standard_normal((1, 3, n * s, n * s)), requires_grad=True)
+        dy = torch.tensor(rng.standard_normal((1, 4, n, n)))
+        (conv2d_same(xb, w, None, (s, s)) * dy).sum().backward()
+        yt = conv2d_transpose_same(dy, w, None, (s, s))
+        assert (yt - xb.grad).abs().max() < 1e-12
+
+
+def test_bilinear_and_blur_restatements_agree():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2, 4, 6, 3))
+    up = F.interpolate(torch.tensor(x).permute(0, 3, 1, 2), scale_factor=2, mode="bilinear",
+                       align_corners=False).permute(0, 2, 3, 1).numpy()
+    assert np.abs(np_ops.upsample2_bilinear_nhwc(x) - up).max() < 1e-12
+    row = np_ops.upsample2_bilinear_nhwc(np.arange(4.0).reshape(1, 1, 4, 1))[0, 0, :, 0]
+    assert np.allclose(row, [0, .25, .75, 1.25, 1.75, 2.25, 2.75, 3])      # SURVEY.md 8(c) recipe
+    from oracle.mvae_oracle import gaussian_blur
+    bl = gaussian_blur(torch.tensor(x).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).numpy()
+    assert np.abs(np_ops.gaussian_blur_nhwc(x) - bl).max() < 1e-12
+
+
+def test_param_census_matches_survey():       # SURVEY.md 8 census table
+    from tests.common import NB
+    for dims, z, enc, want, ntens in [((32, 32, 3), [16] * 3, NB, 1295625, 420), ((32, 32, 3), [16] * 3, None, 2138313, None),
+                                      ((256, 256, 3), [16] * 7, NB, 36045205, 980)]:
+        P, _ = param_table(OracleConfig(dims, z, encoder=enc, decoder=enc))
+        assert sum(int(np.prod(s)) for s, _ in P.values()) == want
+        if ntens:
+            assert len(P) == ntens
+
+
+def test_oracle_gradients_match_finite_differences():
+    """The oracle's autograd gradients are the ELBO's: central differences in float64 on the tiny model."""
+    from tests.common import make_inputs, oracle_config, COMPILE
+    oc = oracle_config("tiny")
+    io = make_inputs("tiny", 3)
+    orc = Oracle(oc)
+    args = (io["state"], io["x"], io["eps"], io["noise"], io["keep"], COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    res, G = orc.loss_and_grads(io["params"], *args)
+    rng = np.random.default_rng(5)
+    for name in ["enc0.conv_base.w", "enc0.b0.mn.se.d1.w", "enc1.mu.w", "dec0.b0.convT.w", "dec1.bn.gamma", "dec0.out.b"]:
+        p = {k: np.asarray(v, np.float64).copy() for k, v in io["params"].items()}
+        idx = tuple(rng.integers(0, s) for s in p[name].shape)
+        h = 1e-5
+        p[name][idx] += h
+        lp = orc.loss_and_grads(p, *args)[0]["loss"]
+        p[name][idx] -= 2 * h
+        lm = orc.loss_and_grads(p, *args)[0]["loss"]
+        fd = (lp - lm) / (2 * h)
+        assert abs(fd - G[name][idx]) <= 1e-4 * max(1.0, abs(fd)), (name, fd, G[name][idx])

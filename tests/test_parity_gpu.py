@@ -1,0 +1,211 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on identical inputs, weights
+and injected epsilon / noise / dropout masks.  Tolerances (fp32 kernels vs float64 oracle), BASELINE.md section 5:
+ELBO terms <= 1e-4 relative, reconstructions <= 1e-4 * 255 absolute, gradients <= 2e-3 relative L2 per tensor
+(sign()/ReLU-mask flips of near-zero values are the noise floor there)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.common import COMPILE, CONFIGS, engine_args, make_inputs, oracle_config, reg_grad, rel_err, ROOT
+
+pytestmark = pytest.mark.gpu
+
+TOL_ELBO = 1e-4
+TOL_RECON_ABS = 1e-4 * 255.0
+TOL_GRAD = 2e-3
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def _engine(name, B):
+    from multiscale_variational_autoencoder_amd.engine import Engine
+    return Engine(**engine_args(name, B)).bind()
+
+
+def _run_pair(name, B, seed=0):
+    from oracle.mvae_oracle import Oracle
+    io = make_inputs(name, B, seed)
+    oc = oracle_config(name)
+    orc = Oracle(oc)
+    inter = {}
+    res, G = orc.loss_and_grads(io["params"], io["state"], io["x"], io["eps"], io["noise"], io["keep"],
+                                COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"], inter=inter)
+    eng = _engine(name, B)
+    eng.set_params(io["params"]); eng.set_state(io["state"])
+    d = {k: eng.to_device(io[k]) for k in ("x", "eps", "noise", "keep")}
+    out = eng.forward(d["x"], True, d["eps"], d["noise"], d["keep"], outputs=("recon", "mu", "log_var", "z", "losses"))
+    eng.backward(COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    eng.torch.cuda.synchronize()
+    return io, oc, orc, res, G, inter, eng, out
+
+
+def _dump(name, report):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_%s.json" % name), "w") as f:
+        json.dump(report, f, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("name,B", [("tiny", 4), ("odd", 3), ("c32def", 4), ("main", 4), ("c32nb", 8), ("c64nb", 2)])
+def test_forward_backward_parity(name, B):
+    io, oc, orc, res, G, inter, eng, out = _run_pair(name, B)
+    rep = {}
+    # ---- saved intermediates, layer by layer (first failing layer localises a kernel bug)
+    for k, v in inter.items():
+        nm = k[:-4] if k.endswith(".out") and False else k
+        try:
+            t = eng.tensor(nm, B).cpu().numpy()
+        except KeyError:
+            continue
+        ref = v.detach().numpy()
+        if ref.ndim == 4:
+            ref = np.transpose(ref, (0, 2, 3, 1))
+        rep["fwd/" + k] = rel_err(t.reshape(ref.shape), ref)
+    losses = out["losses"].cpu().numpy().astype(np.float64)
+    rep["loss/r"] = rel_err(losses[:, 0], res["r"]); rep["loss/r_exp"] = rel_err(losses[:, 1], res["r_exp"])
+    rep["loss/kl"] = rel_err(losses[:, 2], res["kl"])
+    for s in range(oc.levels):
+        rep["loss/kl_scale%d" % s] = rel_err(losses[:, 3 + s], res["kl_scale"][:, s])
+    elbo_gpu = (COMPILE["r_loss_factor"] * losses[:, 1] + COMPILE["kl_loss_factor"] * losses[:, 2]).mean()
+    rep["loss/elbo_rel"] = abs(elbo_gpu - res["data_loss"]) / abs(res["data_loss"])
+    rep["loss/reg_rel"] = abs(eng.reg_loss() - res["reg_loss"]) / max(abs(res["reg_loss"]), 1e-30)
+    rep["recon_abs"] = float(np.abs(out["recon"].cpu().numpy() - res["recon"]).max())
+    for k in ("mu", "log_var", "z"):
+        rep["out/" + k] = rel_err(out[k].cpu().numpy(), res[k])
+    grads = eng.get_grads()
+    rg = reg_grad(io["params"], eng.param_table)
+    worst = ("", 0.0)
+    for k in G:
+        e = rel_err(grads[k].astype(np.float64) + rg[k], G[k])
+        rep["grad/" + k] = e
+        if e > worst[1]:
+            worst = (k, e)
+    m = eng.metrics()
+    rep["metrics/r"] = abs(m["vae_r_loss"] - res["r"].mean()) / abs(res["r"].mean())
+    rep["metrics/kl"] = abs(m["vae_kl_loss"] - res["kl"].mean()) / abs(res["kl"].mean())
+    _dump(name, rep)
+    bad_fwd = {k: v for k, v in rep.items() if k.startswith("fwd/") and v > 1e-4}
+    assert not bad_fwd, bad_fwd
+    assert rep["recon_abs"] <= TOL_RECON_ABS, rep["recon_abs"]
+    for k in ("loss/r", "loss/r_exp", "loss/kl", "loss/elbo_rel", "loss/reg_rel", "metrics/r", "metrics/kl"):
+        assert rep[k] <= TOL_ELBO, (k, rep[k])
+    bad = {k: v for k, v in rep.items() if k.startswith("grad/") and v > TOL_GRAD}
+    assert not bad, (worst, len(bad), dict(list(bad.items())[:12]))
+
+
+@pytest.mark.parametrize("name,B", [("tiny", 4), ("c32nb", 4)])
+def test_adagrad_trajectory_parity(name, B):
+    """3 optimiser steps (per-variable clipnorm, Adagrad a0=0.1, BN moving statistics) against the oracle."""
+    from oracle.mvae_oracle import Oracle
+    io = make_inputs(name, B)
+    oc = oracle_config(name)
+    orc = Oracle(oc)
+    eng = _engine(name, B)
+    eng.set_params(io["params"]); eng.set_state(io["state"])
+    p = {k: np.asarray(v, np.float64) for k, v in io["params"].items()}
+    a = {k: np.full(v.shape, 0.1) for k, v in p.items()}
+    st = {k: np.asarray(v, np.float64) for k, v in io["state"].items()}
+    rep = {}
+    for step in range(3):
+        stp = make_inputs(name, B, seed=step)
+        d = {k: eng.to_device(stp[k]) for k in ("x", "eps", "noise", "keep")}
+        eng.train_step(d["x"], COMPILE["learning_rate"], COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"],
+                       COMPILE["clip_norm"], eps=d["eps"], noise=d["noise"], keep_mask=d["keep"])
+        res, G, p, a, st = orc.train_step(p, a, st, stp["x"], stp["eps"], stp["noise"], stp["keep"],
+                                          COMPILE["learning_rate"], COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"],
+                                          COMPILE["clip_norm"])
+        gp, ga, gs = eng.get_params(), eng.get_accum(), eng.get_state()
+        rep["step%d/param" % step] = max(rel_err(gp[k], p[k]) for k in p)
+        rep["step%d/update" % step] = max(rel_err(gp[k].astype(np.float64) - io["params"][k], p[k] - io["params"][k])
+                                          for k in p if np.abs(p[k] - io["params"][k]).max() > 0)
+        rep["step%d/accum" % step] = max(rel_err(ga[k], a[k]) for k in a)
+        rep["step%d/state" % step] = max(rel_err(gs[k], st[k]) for k in st)
+    _dump("traj_" + name, rep)
+    for k, v in rep.items():
+        tol = 5e-3 if "update" in k else 1e-4
+        assert v <= tol, (k, v, rep)
+
+
+@pytest.mark.parametrize("name,B", [("tiny", 4), ("c32nb", 4)])
+def test_inference_parity(name, B):
+    """model_trainable / encoder / decoder .predict: no noise/dropout, BN moving statistics, sampling still on."""
+    from oracle.mvae_oracle import Oracle
+    io = make_inputs(name, B)
+    orc = Oracle(oracle_config(name))
+    ref = orc.predict(io["params"], io["state"], io["x"], io["eps"])
+    eng = _engine(name, B)
+    eng.set_params(io["params"]); eng.set_state(io["state"])
+    out = eng.forward(eng.to_device(io["x"]), False, eng.to_device(io["eps"]), outputs=("recon", "z", "mu"))
+    assert np.abs(out["recon"].cpu().numpy() - ref["recon"]).max() <= TOL_RECON_ABS
+    assert rel_err(out["z"].cpu().numpy(), ref["z"]) <= 1e-5
+    T = orc.tensors(io["params"])
+    import torch
+    with torch.no_grad():
+        dec = orc.decode(T, io["state"], ref["z"]).numpy()
+    got = eng.decode(eng.to_device(ref["z"])).cpu().numpy()
+    assert np.abs(got - dec).max() <= TOL_RECON_ABS
+    assert np.abs(got - ref["recon"]).max() <= TOL_RECON_ABS       # decoder(encoder(x)) == trainable(x)
+
+
+def test_golden_fixture_tiny():
+    """The committed fixture (tests/golden/tiny_case.npz, generated by tests/golden/make_golden.py from the oracle)."""
+    f = np.load(os.path.join(ROOT, "tests", "golden", "tiny_case.npz"))
+    io = make_inputs("tiny", 4)
+    assert np.array_equal(f["x"], io["x"])
+    eng = _engine("tiny", 4)
+    eng.set_params({k: f["p/" + k] for k in eng.param_table}); eng.set_state(io["state"])
+    d = {k: eng.to_device(f[k]) for k in ("x", "eps", "noise", "keep")}
+    out = eng.forward(d["x"], True, d["eps"], d["noise"], d["keep"], outputs=("recon", "losses"))
+    eng.backward(COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    assert np.abs(out["recon"].cpu().numpy() - f["recon"]).max() <= TOL_RECON_ABS
+    assert rel_err(out["losses"].cpu().numpy()[:, :3], f["losses"]) <= TOL_ELBO
+    g = eng.get_grads()
+    for k in eng.param_table:
+        assert rel_err(g[k], f["g/" + k]) <= TOL_GRAD, k
+
+
+def test_device_rng_statistics():
+    """Timed runs draw epsilon / noise / dropout with Philox on the device: check the distributions."""
+    eng = _engine("c32nb", 256)
+    x = eng.to_device(np.random.default_rng(0).uniform(0, 255, (256, 32, 32, 3)))
+    out = eng.forward(x, True, seed=1234, outputs=("mu", "log_var", "z"))
+    eng.torch.cuda.synchronize()
+    eps = eng.tensor("eps", 256).cpu().numpy()
+    assert abs(eps.mean()) < 3 * 0.01 / np.sqrt(eps.size) * 3 and abs(eps.std() / 0.01 - 1) < 0.03
+    z = out["z"].cpu().numpy(); mu = out["mu"].cpu().numpy(); lv = out["log_var"].cpu().numpy()
+    assert rel_err(z, mu + np.exp(lv) * eps) < 1e-5
+    noise = eng.tensor("noise", 256).cpu().numpy()
+    assert abs(noise.mean()) < 0.01 and abs(noise.std() - 1) < 0.01
+    keep = eng.tensor("keep_mask", 256).cpu().numpy()
+    assert set(np.unique(keep)) <= {0.0, 1.0} and abs(keep.mean() - 0.9) < 0.05
+    out2 = eng.forward(x, True, seed=1235, outputs=("z",))
+    assert not np.array_equal(out2["z"].cpu().numpy(), z)
+
+
+def test_full_size_properties_c32nb_b512():
+    """BASELINE config 2 (C32-nb, B=512) at full size: size-independent properties instead of the (slow) oracle --
+    finite outputs, recon in range, per-sample independence of everything outside BatchNorm (batch-permutation
+    equivariance of the loss vector), and the loss goes down under the optimiser."""
+    from multiscale_variational_autoencoder_amd.initializers import init_params
+    B = 512
+    eng = _engine("c32nb", B)
+    eng.set_params(init_params(eng.param_table, 42))
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 255, (B, 32, 32, 3)).astype(np.float32)
+    eps = (rng.standard_normal((B, 48)) * 0.01).astype(np.float32)
+    xd, ed = eng.to_device(x), eng.to_device(eps)
+    o1 = eng.forward(xd, False, ed, outputs=("recon", "losses"))
+    r1, l1 = o1["recon"].cpu().numpy(), o1["losses"].cpu().numpy()
+    assert np.isfinite(r1).all() and r1.min() >= 0.0 and r1.max() <= 255.0 and np.isfinite(l1).all()
+    perm = rng.permutation(B)
+    o2 = eng.forward(eng.to_device(x[perm]), False, eng.to_device(eps[perm]), outputs=("losses",))
+    assert rel_err(o2["losses"].cpu().numpy(), l1[perm]) < 1e-5
+    first = last = None
+    for step in range(12):
+        eng.train_step(xd, 0.01, COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"], 1.0, seed=step)
+        m = eng.metrics()
+        val = 1000.0 * m["r_exp"] + 10.0 * m["vae_kl_loss"]
+        first = val if first is None else first
+        last = val
+    assert np.isfinite(last) and last < first, (first, last)
+    assert np.isfinite(eng.params.cpu().numpy()).all()
