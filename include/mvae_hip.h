@@ -132,6 +132,12 @@ int mvae_reg_loss(mvae_handle* h, float* out_dev, void* stream);
 /* decoder model (multiscale_vae.py:247-257): z [B,sum z] -> recon [B,H,W,C], inference mode. */
 int mvae_decode(mvae_handle* h, const float* z, int32_t batch, float* recon, void* stream);
 
+/* ---- diagnostics (process-global): per-launch HIP-event timing on the launch stream, used by bench.py for
+ *      the per-kernel roofline line.  report writes a JSON object {tag: {count, ms, bytes, flops}} (algorithmic
+ *      bytes / flops summed over the launches), returns its length, and clears the records; it synchronises. ---- */
+int mvae_profile_enable(int32_t on);
+int64_t mvae_profile_report(char* buf, int64_t cap);
+
 /* ---- debugging / parity: look up a saved intermediate of the last forward by name ---- */
 int mvae_tensor_lookup(const mvae_handle* h, const char* name, float** ptr, int64_t* elems_per_image);
 

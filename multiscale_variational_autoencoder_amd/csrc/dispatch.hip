@@ -1,8 +1,16 @@
 // dispatch.hip -- chooses, per op and shape, between the shape-generic kernels (kernels_generic.hip) and
 // the LDS/MFMA-tiled gfx950 kernels (kernels_mfma.hip).  Both are device paths; there is no CPU fallback.
 #include "kernels.h"
+#include "prof.h"
 
 namespace mvae {
+
+Profiler& profiler() {
+  static Profiler p;
+  return p;
+}
+
+static inline double f4(double n) { return 4.0 * n; }
 
 void launch_conv_f_generic(const float*, const float*, const float*, const float*, float*, ConvGeom, PreOp, int,
                            hipStream_t);
@@ -21,41 +29,58 @@ void launch_gemm_tn_generic(const float*, const float*, float*, float*, int, int
 
 void launch_conv_f(const float* big, const float* w, const float* bias, const float* residual, float* small,
                    ConvGeom g, PreOp pre, int act, hipStream_t s) {
+  double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
+  ProfScope ps(g.KH * g.KW == 1 ? "conv1x1_f" : "convkxk_f", f4(nb + ns * (residual ? 2 : 1) + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
   launch_conv_f_generic(big, w, bias, residual, small, g, pre, act, s);
 }
 void launch_conv_t(const float* small, const float* w, const float* bias, const float* residual, float* big,
                    ConvGeom g, hipStream_t s) {
+  double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
+  ProfScope ps(g.KH * g.KW == 1 ? "conv1x1_t" : "convkxk_t", f4(ns + nb * (residual ? 2 : 1) + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
   launch_conv_t_generic(small, w, bias, residual, big, g, s);
 }
 void launch_conv_wgrad(const float* big, const float* small, float* dW, ConvGeom g, PreOp pre, hipStream_t s) {
+  double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
+  ProfScope ps(g.KH * g.KW == 1 ? "conv1x1_wgrad" : "convkxk_wgrad", f4(nb + ns + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
   launch_conv_wgrad_generic(big, small, dW, g, pre, s);
 }
 void launch_dw_fwd(const float* in, const float* w, const float* b, float* out, int B, int H, int W, int C,
                    hipStream_t s) {
+  double n = (double)B * H * W * C;
+  ProfScope ps("dw_fwd", f4(2 * n), 18.0 * n, s);
   launch_dw_fwd_generic(in, w, b, out, B, H, W, C, s);
 }
 void launch_dw_bwd_data(const float* dy, const float* w, const float* mask_src, float* dx, int B, int H, int W,
                         int C, hipStream_t s) {
+  double n = (double)B * H * W * C;
+  ProfScope ps("dw_bwd_data", f4(3 * n), 18.0 * n, s);
   launch_dw_bwd_data_generic(dy, w, mask_src, dx, B, H, W, C, s);
 }
 void launch_dw_wgrad(const float* in, const float* dy, float* dW, float* db, int B, int H, int W, int C,
                      hipStream_t s) {
+  double n = (double)B * H * W * C;
+  ProfScope ps("dw_wgrad", f4(2 * n), 20.0 * n, s);
   launch_dw_wgrad_generic(in, dy, dW, db, B, H, W, C, s);
 }
 void launch_mn_dt1pre(float* d, const float* t1, const float* g, const float* dgap, int B, int64_t HW, int C,
                       float inv_hw, hipStream_t s) {
+  double n = (double)B * HW * C;
+  ProfScope ps("mn_dt1pre", f4(3 * n), 3.0 * n, s);
   launch_mn_dt1pre_generic(d, t1, g, dgap, B, HW, C, inv_hw, s);
 }
 void launch_gemm_nn(const float* a, const float* w, const float* bias, float* out, float* out_lin, int B, int K,
                     int N, int act, hipStream_t s) {
+  ProfScope ps("gemm_nn", f4((double)B * K + (double)K * N + (double)B * N), 2.0 * B * K * N, s);
   launch_gemm_nn_generic(a, w, bias, out, out_lin, B, K, N, act, s);
 }
 void launch_gemm_nt(const float* a, const float* w, float* out, int B, int K, int N, const float* hs_lin,
                     int accumulate, hipStream_t s) {
+  ProfScope ps("gemm_nt", f4((double)B * K + (double)K * N + (double)B * N), 2.0 * B * K * N, s);
   launch_gemm_nt_generic(a, w, out, B, K, N, hs_lin, accumulate, s);
 }
 void launch_gemm_tn(const float* a, const float* g, float* dW, float* db, int B, int K, int N, const float* a_scale,
                     const float* a_shift, const float* hs_lin, hipStream_t s) {
+  ProfScope ps("gemm_tn", f4((double)B * K + (double)K * N + (double)B * N), 2.0 * B * K * N, s);
   launch_gemm_tn_generic(a, g, dW, db, B, K, N, a_scale, a_shift, hs_lin, s);
 }
 

@@ -6,6 +6,7 @@
 // no autograd -- every backward step is written out against the forward it inverts.
 #include "../../include/mvae_hip.h"
 #include "kernels.h"
+#include "prof.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -779,6 +780,40 @@ int mvae_decode(mvae_handle* h, const float* z, int32_t batch, float* recon, voi
   merge_forward(h, batch, recon, s);
   h->last_B = 0;   // activations no longer belong to a training forward
   return check_launch(h, "mvae_decode");
+}
+
+int mvae_profile_enable(int32_t on) {
+  Profiler& p = profiler();
+  p.on = on != 0;
+  return MVAE_OK;
+}
+
+int64_t mvae_profile_report(char* buf, int64_t cap) {
+  Profiler& p = profiler();
+  if (hipDeviceSynchronize() != hipSuccess) return MVAE_E_HIP;
+  struct Agg { int64_t n = 0; double ms = 0, bytes = 0, flops = 0; };
+  std::vector<Agg> agg(p.tags.size());
+  for (ProfRec& r : p.recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      Agg& a = agg[r.tag];
+      a.n++; a.ms += ms; a.bytes += r.bytes; a.flops += r.flops;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  p.recs.clear();
+  std::string out = "{";
+  for (size_t i = 0; i < agg.size(); ++i) {
+    if (!agg[i].n) continue;
+    char line[256];
+    snprintf(line, sizeof(line), "%s\"%s\": {\"count\": %lld, \"ms\": %.6f, \"bytes\": %.1f, \"flops\": %.1f}",
+             out.size() > 1 ? ", " : "", p.tags[i].c_str(), (long long)agg[i].n, agg[i].ms, agg[i].bytes, agg[i].flops);
+    out += line;
+  }
+  out += "}";
+  if (buf && cap > 0) { strncpy(buf, out.c_str(), (size_t)cap - 1); buf[cap - 1] = 0; }
+  return (int64_t)out.size();
 }
 
 int mvae_tensor_lookup(const mvae_handle* h, const char* name, float** ptr, int64_t* elems_per_image) {
