@@ -55,7 +55,11 @@ def cpu_baseline(wname, seconds=20.0):
     from multiscale_variational_autoencoder_amd.initializers import init_params, init_state
     from collections import OrderedDict
     w = WORKLOADS[wname]
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))     # a 1-GPU box grants a 16-core share; more threads only oversubscribe it
     torch.set_num_threads(cores)
     oc = OracleConfig(w["input_dims"], w["z_dims"], encoder=w["encoder"], decoder=w["decoder"])
     P, S = param_table(oc)
@@ -75,6 +79,7 @@ def cpu_baseline(wname, seconds=20.0):
     n, t0 = 0, time.time()
     while time.time() - t0 < seconds and n < 50:
         step(); n += 1
+        sys.stderr.write("cpu_baseline step %d  %.1fs\n" % (n, time.time() - t0)); sys.stderr.flush()
     dt = time.time() - t0
     return dict(value=Bc * n / dt, unit="images/sec", cores=cores, kind="port",
                 sample="%d train steps of batch %d (%s, fp32, torch-CPU restatement oracle/mvae_oracle.py, %d threads)"

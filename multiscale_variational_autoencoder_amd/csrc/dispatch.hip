@@ -26,23 +26,33 @@ void launch_gemm_nn_generic(const float*, const float*, const float*, float*, fl
 void launch_gemm_nt_generic(const float*, const float*, float*, int, int, int, const float*, int, hipStream_t);
 void launch_gemm_tn_generic(const float*, const float*, float*, float*, int, int, int, const float*, const float*,
                             const float*, hipStream_t);
+bool launch_conv1x1_mfma(bool transposed, const float* in, const float* w, const float* bias, const float* residual,
+                         float* out, const ConvGeom& g, PreOp pre, int act, hipStream_t s);
+bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, PreOp pre,
+                            hipStream_t s);
 
 void launch_conv_f(const float* big, const float* w, const float* bias, const float* residual, float* small,
                    ConvGeom g, PreOp pre, int act, hipStream_t s) {
   double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
   ProfScope ps(g.KH * g.KW == 1 ? "conv1x1_f" : "convkxk_f", f4(nb + ns * (residual ? 2 : 1) + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
+  if (launch_conv1x1_mfma(false, big, w, bias, residual, small, g, pre, act, s)) return;
   launch_conv_f_generic(big, w, bias, residual, small, g, pre, act, s);
 }
 void launch_conv_t(const float* small, const float* w, const float* bias, const float* residual, float* big,
                    ConvGeom g, hipStream_t s) {
   double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
   ProfScope ps(g.KH * g.KW == 1 ? "conv1x1_t" : "convkxk_t", f4(ns + nb * (residual ? 2 : 1) + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
+  PreOp none{nullptr, nullptr, nullptr};
+  if (launch_conv1x1_mfma(true, small, w, bias, residual, big, g, none, ACT_NONE, s)) return;
   launch_conv_t_generic(small, w, bias, residual, big, g, s);
 }
-void launch_conv_wgrad(const float* big, const float* small, float* dW, ConvGeom g, PreOp pre, hipStream_t s) {
+void launch_conv_wgrad(const float* big, const float* small, float* dW, float* db, ConvGeom g, PreOp pre,
+                       hipStream_t s) {
   double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
   ProfScope ps(g.KH * g.KW == 1 ? "conv1x1_wgrad" : "convkxk_wgrad", f4(nb + ns + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
+  if (launch_conv_wgrad_mfma(big, small, dW, db, g, pre, s)) return;
   launch_conv_wgrad_generic(big, small, dW, g, pre, s);
+  if (db) launch_colsum(small, db, (int64_t)g.B * g.OH * g.OW, g.CO, s);
 }
 void launch_dw_fwd(const float* in, const float* w, const float* b, float* out, int B, int H, int W, int C,
                    hipStream_t s) {

@@ -38,8 +38,9 @@ void launch_conv_f(const float* big, const float* w, const float* bias, const fl
 // big = convT(small) + bias + residual      (conv backward-data / Conv2DTranspose forward)
 void launch_conv_t(const float* small, const float* w, const float* bias, const float* residual, float* big,
                    ConvGeom g, hipStream_t s);
-// dW[kh,kw,ci,co] += sum pre(big) * small      (dW pre-zeroed by the caller)
-void launch_conv_wgrad(const float* big, const float* small, float* dW, ConvGeom g, PreOp pre, hipStream_t s);
+// dW[kh,kw,ci,co] += sum pre(big) * small ; db[co] += sum small (db nullable)   (both pre-zeroed by the caller)
+void launch_conv_wgrad(const float* big, const float* small, float* dW, float* db, ConvGeom g, PreOp pre,
+                       hipStream_t s);
 // ELU backward in place: d *= (y > 0 ? 1 : y + 1)
 void launch_elu_bwd(float* d, const float* y, int64_t n, hipStream_t s);
 

@@ -3,6 +3,7 @@
 // kernels_mfma.hip take over the wide-channel shapes.  Reference semantics: mvae/multiscale_vae.py and
 // mvae/layer_blocks.py (line cites at each kernel).  Wave = 64 lanes; blocks are multiples of 64.
 #include "kernels.h"
+#include "prof.h"
 
 namespace mvae {
 
@@ -88,10 +89,12 @@ __global__ void k_rng_keepmask(float* out, int64_t n, float p_drop, uint64_t see
   }
 }
 void launch_rng_normal(float* out, int64_t n, float stddev, uint64_t seed, uint32_t sid, hipStream_t s) {
+  ProfScope ps("rng", (double)(4.0*n), 0.0, s);
   if (n <= 0) return;
   hipLaunchKernelGGL(k_rng_normal, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, s, out, n, stddev, seed, sid);
 }
 void launch_rng_keepmask(float* out, int64_t n, float p_drop, uint64_t seed, uint32_t sid, hipStream_t s) {
+  ProfScope ps("rng", (double)(4.0*n), 0.0, s);
   if (n <= 0) return;
   hipLaunchKernelGGL(k_rng_keepmask, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, s, out, n, p_drop, seed, sid);
 }
@@ -115,6 +118,7 @@ __global__ void k_prep(const float* __restrict__ x, const float* __restrict__ no
 }
 void launch_prep(const float* x, const float* noise, const float* keep, float* out, int B, int H, int W, int C,
                  float v0, float v1, float noise_std, float keep_scale, hipStream_t s) {
+  ProfScope ps("pyramid", (double)(8.0*B*H*W*C), 0.0, s);
   int64_t per = (int64_t)H * W * C, n = per * B;
   hipLaunchKernelGGL(k_prep, dim3(grid_for(n)), dim3(kBlock), 0, s, x, noise, keep, out, n, per, C, v0,
                      2.0f / (v1 - v0), noise_std, keep_scale);
@@ -154,6 +158,7 @@ __global__ void k_blur_split(const float* __restrict__ in, float* __restrict__ b
   }
 }
 void launch_blur_split(const float* in, float* band, float* down, int B, int H, int W, int C, hipStream_t s) {
+  ProfScope ps("pyramid", (double)(10.0*B*H*W*C), 0.0, s);
   int64_t n = (int64_t)B * H * W * C;
   hipLaunchKernelGGL(k_blur_split, dim3(grid_for(n)), dim3(kBlock), 0, s, in, band, down, B, H, W, C, H / 2, W / 2);
 }
@@ -318,6 +323,7 @@ __global__ void k_elu_bwd(float* d, const float* y, int64_t n) {
   }
 }
 void launch_elu_bwd(float* d, const float* y, int64_t n, hipStream_t s) {
+  ProfScope ps("elu_bwd", (double)(12.0*n), 0.0, s);
   hipLaunchKernelGGL(k_elu_bwd, dim3(grid_for(n)), dim3(kBlock), 0, s, d, y, n);
 }
 
@@ -490,9 +496,11 @@ static void launch_spatial(const float* a, const float* b, float* out, int B, in
                      C, cpb, scale, ppb, chunks > 1 ? 1 : 0);
 }
 void launch_spatial_sum(const float* x, float* out, int B, int64_t HW, int C, float scale, hipStream_t s) {
+  ProfScope ps("spatial_reduce", (double)(4.0*B*HW*C), 0.0, s);
   launch_spatial<0>(x, nullptr, out, B, HW, C, scale, s);
 }
 void launch_spatial_dot(const float* a, const float* b, float* out, int B, int64_t HW, int C, hipStream_t s) {
+  ProfScope ps("spatial_reduce", (double)(8.0*B*HW*C), 0.0, s);
   launch_spatial<1>(a, b, out, B, HW, C, 1.0f, s);
 }
 
@@ -535,9 +543,11 @@ static void launch_colreduce(F f, float* out, int64_t M, int C, hipStream_t s) {
                      rpb);
 }
 void launch_colsum(const float* x, float* out, int64_t M, int C, hipStream_t s) {
+  ProfScope ps("col_reduce", (double)(4.0*M*C), 0.0, s);
   launch_colreduce(FnSum{x}, out, M, C, s);
 }
 void launch_colsqdev(const float* x, const float* mean, float* out, int64_t M, int C, hipStream_t s) {
+  ProfScope ps("col_reduce", (double)(4.0*M*C), 0.0, s);
   launch_colreduce(FnSqDev{x, mean}, out, M, C, s);
 }
 struct FnBnD {
@@ -552,6 +562,7 @@ struct FnBnDx {
 };
 void launch_bn_bwd_reduce(const float* d, const float* x, const float* mean, const float* invstd, float* sum_d,
                           float* sum_dx, int64_t M, int C, hipStream_t s) {
+  ProfScope ps("col_reduce", (double)(16.0*M*C), 0.0, s);
   launch_colreduce(FnBnD{d}, sum_d, M, C, s);
   launch_colreduce(FnBnDx{d, x, mean, invstd}, sum_dx, M, C, s);
 }
@@ -696,6 +707,7 @@ __global__ void __launch_bounds__(256) k_bn1d_fwd(const float* __restrict__ x, c
 void launch_bn1d_fwd(const float* x, const float* gamma, const float* beta, const float* mov_mean,
                      const float* mov_var, float* xhat, float* invstd, float* y, float* stat_mean, float* stat_var,
                      int B, int C, float eps, int training, hipStream_t s) {
+  ProfScope ps("bn1d", (double)(12.0*B*C), 0.0, s);
   hipLaunchKernelGGL(k_bn1d_fwd, dim3(C), dim3(256), 0, s, x, gamma, beta, mov_mean, mov_var, xhat, invstd, y,
                      stat_mean, stat_var, B, C, eps, training);
 }
@@ -731,6 +743,7 @@ __global__ void __launch_bounds__(256) k_bn1d_bwd(const float* __restrict__ dy, 
 }
 void launch_bn1d_bwd(const float* dy, const float* xhat, const float* invstd, const float* gamma,
                      const float* relu_src, float* dx, float* dgamma, float* dbeta, int B, int C, hipStream_t s) {
+  ProfScope ps("bn1d", (double)(16.0*B*C), 0.0, s);
   hipLaunchKernelGGL(k_bn1d_bwd, dim3(C), dim3(256), 0, s, dy, xhat, invstd, gamma, relu_src, dx, dgamma, dbeta, B, C);
 }
 
@@ -757,6 +770,7 @@ __global__ void k_bn2d_finalize(const float* sum, const float* sqdev, const floa
 }
 void launch_bn2d_mean(const float* sum, const float* mov_mean, float* mean, int64_t M, int C, int training,
                       hipStream_t s) {
+  ProfScope ps("bn2d_small", (double)(0.0), 0.0, s);
   hipLaunchKernelGGL(k_bn2d_finalize, dim3((C + 63) / 64), dim3(64), 0, s, sum, nullptr, nullptr, nullptr, mov_mean,
                      nullptr, mean, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f / (float)M, C, 0.f, training, 0);
 }
@@ -764,6 +778,7 @@ void launch_bn2d_finalize(const float* sum, const float* sqdev, const float* gam
                           const float* mov_mean, const float* mov_var, float* mean, float* invstd, float* scale,
                           float* shift, float* stat_mean, float* stat_var, int64_t M, int C, float eps, int training,
                           hipStream_t s) {
+  ProfScope ps("bn2d_small", (double)(0.0), 0.0, s);
   hipLaunchKernelGGL(k_bn2d_finalize, dim3((C + 63) / 64), dim3(64), 0, s, sum, sqdev, gamma, beta, mov_mean, mov_var,
                      mean, invstd, scale, shift, stat_mean, stat_var, 1.0f / (float)M, C, eps, training, 1);
 }
@@ -785,6 +800,7 @@ __global__ void k_add_vec2(float* o0, const float* a0, float* o1, const float* a
 void launch_bn2d_bwd_apply(float* d, const float* x, const float* mean, const float* invstd, const float* gamma,
                            const float* sum_d, const float* sum_dx, float* dgamma, float* dbeta, int64_t M, int C,
                            hipStream_t s) {
+  ProfScope ps("bn2d_apply", (double)(12.0*M*C), 0.0, s);
   int64_t n = M * C;
   hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3(grid_for(n)), dim3(kBlock), 0, s, d, x, mean, invstd, gamma, sum_d, sum_dx,
                      n, C, 1.0f / (float)M);
@@ -817,6 +833,7 @@ __global__ void k_sample_kl(const float* __restrict__ mu, const float* __restric
 }
 void launch_sample_kl(const float* mu, const float* lv, const float* eps, int eps_stride, int eps_off, float* z,
                       float* kl_out, int kl_stride, int kl_col, int B, int Z, hipStream_t s) {
+  ProfScope ps("latent", (double)(16.0*B*Z), 0.0, s);
   hipLaunchKernelGGL(k_sample_kl, dim3((B + 63) / 64), dim3(64), 0, s, mu, lv, eps, eps_stride, eps_off, z, kl_out,
                      kl_stride, kl_col, B, Z);
 }
@@ -835,6 +852,7 @@ __global__ void k_sample_kl_bwd(const float* __restrict__ dz, const float* __res
 }
 void launch_sample_kl_bwd(const float* dz, const float* mu, const float* lv, const float* eps, int eps_stride,
                           int eps_off, float* dmu, float* dlv, float kf_over_b, int B, int Z, hipStream_t s) {
+  ProfScope ps("latent", (double)(24.0*B*Z), 0.0, s);
   hipLaunchKernelGGL(k_sample_kl_bwd, dim3(grid_for((int64_t)B * Z)), dim3(kBlock), 0, s, dz, mu, lv, eps, eps_stride,
                      eps_off, dmu, dlv, kf_over_b, B, Z);
 }
@@ -848,6 +866,7 @@ __global__ void k_copy_cols(const float* src, int ss, int so, float* dst, int ds
 }
 void launch_copy_cols(const float* src, int src_stride, int src_off, float* dst, int dst_stride, int dst_off, int B,
                       int n, hipStream_t s) {
+  ProfScope ps("latent", (double)(8.0*B*n), 0.0, s);
   hipLaunchKernelGGL(k_copy_cols, dim3(grid_for((int64_t)B * n)), dim3(kBlock), 0, s, src, src_stride, src_off, dst,
                      dst_stride, dst_off, B, n);
 }
@@ -884,6 +903,7 @@ __global__ void k_upsample_add(const float* __restrict__ coarse, const float* __
 }
 void launch_upsample_add(const float* coarse, const float* fine_in, float* fine_out, float* recon, int B, int H,
                          int W, int C, float v0, float v1, hipStream_t s) {
+  ProfScope ps("merge", (double)(12.0*B*H*W*C), 0.0, s);
   int64_t n = (int64_t)B * H * W * C;
   hipLaunchKernelGGL(k_upsample_add, dim3(grid_for(n)), dim3(kBlock), 0, s, coarse, fine_in, fine_out, recon, B, H, W,
                      C, v0, v1);
@@ -916,6 +936,7 @@ __global__ void k_upsample_bwd(const float* __restrict__ fg, float* __restrict__
   }
 }
 void launch_upsample_bwd(const float* fine_grad, float* coarse_grad, int B, int h, int w, int C, hipStream_t s) {
+  ProfScope ps("merge", (double)(20.0*B*h*w*C), 0.0, s);
   int64_t n = (int64_t)B * h * w * C;
   hipLaunchKernelGGL(k_upsample_bwd, dim3(grid_for(n)), dim3(kBlock), 0, s, fine_grad, coarse_grad, B, h, w, C);
 }
@@ -984,6 +1005,7 @@ static void crop_box(int H, int W, int* cy0, int* cy1, int* cx0, int* cx1) {
 }
 void launch_loss_fwd(const float* y, const float* recon, float* losses, int loss_stride, int nscales, float* sgn,
                      int B, int H, int W, int C, hipStream_t s) {
+  ProfScope ps("loss", (double)(8.0*B*H*W*C), 0.0, s);
   int cy0, cy1, cx0, cx1;
   crop_box(H, W, &cy0, &cy1, &cx0, &cx1);
   hipLaunchKernelGGL(k_loss_fwd, dim3(B), dim3(256), 0, s, y, recon, losses, loss_stride, nscales, sgn, H, W, C, cy0,
@@ -1017,6 +1039,7 @@ __global__ void k_loss_bwd(const float* __restrict__ y, const float* __restrict_
 }
 void launch_loss_bwd(const float* y, const float* recon, const float* merged, const float* sgn, float* du, int B,
                      int H, int W, int C, float v0, float v1, float rf_over_b, hipStream_t s) {
+  ProfScope ps("loss", (double)(16.0*B*H*W*C), 0.0, s);
   int cy0, cy1, cx0, cx1;
   crop_box(H, W, &cy0, &cy1, &cx0, &cx1);
   int64_t n = (int64_t)B * H * W * C;
@@ -1036,6 +1059,7 @@ __global__ void __launch_bounds__(256) k_metrics(const float* __restrict__ losse
   }
 }
 void launch_metrics(const float* losses, int ncol, int B, float* metrics, hipStream_t s) {
+  ProfScope ps("loss", (double)(0.0), 0.0, s);
   hipLaunchKernelGGL(k_metrics, dim3(ncol), dim3(256), 0, s, losses, ncol, B, metrics);
 }
 
@@ -1061,6 +1085,7 @@ __global__ void __launch_bounds__(256) k_opt_prepare(const float* __restrict__ w
 }
 void launch_opt_prepare(const float* w, float* g, const ChunkDesc* chunks, int nchunks, float* norms,
                         float grad_scale, hipStream_t s) {
+  ProfScope ps("optimizer", (double)(0.0), 0.0, s);
   hipLaunchKernelGGL(k_opt_prepare, dim3(nchunks), dim3(256), 0, s, w, g, chunks, norms, grad_scale);
 }
 __global__ void __launch_bounds__(256) k_opt_apply(float* __restrict__ w, const float* __restrict__ g,
@@ -1082,6 +1107,7 @@ __global__ void __launch_bounds__(256) k_opt_apply(float* __restrict__ w, const 
 }
 void launch_opt_apply(float* w, const float* g, float* a, const ChunkDesc* chunks, int nchunks, const float* norms,
                       float lr, float clip_norm, hipStream_t s) {
+  ProfScope ps("optimizer", (double)(0.0), 0.0, s);
   hipLaunchKernelGGL(k_opt_apply, dim3(nchunks), dim3(256), 0, s, w, g, a, chunks, norms, lr, clip_norm);
 }
 __global__ void __launch_bounds__(256) k_reg_loss(const float* __restrict__ w, const ChunkDesc* __restrict__ chunks,
@@ -1098,6 +1124,7 @@ __global__ void __launch_bounds__(256) k_reg_loss(const float* __restrict__ w, c
   if (threadIdx.x == 0) atomicAdd(out, 0.01f * t);
 }
 void launch_reg_loss(const float* w, const ChunkDesc* chunks, int nchunks, float* out, hipStream_t s) {
+  ProfScope ps("optimizer", (double)(0.0), 0.0, s);
   hipLaunchKernelGGL(k_reg_loss, dim3(nchunks), dim3(256), 0, s, w, chunks, out);
 }
 __global__ void k_state_update(float* __restrict__ state, const float* __restrict__ stats,
@@ -1115,6 +1142,7 @@ __global__ void k_state_update(float* __restrict__ state, const float* __restric
 }
 void launch_state_update(float* state, const float* stats, const StateDesc* descs, int ndesc, float stat_scale,
                          int B, hipStream_t s) {
+  ProfScope ps("optimizer", (double)(0.0), 0.0, s);
   if (ndesc <= 0) return;
   hipLaunchKernelGGL(k_state_update, dim3(ndesc), dim3(64), 0, s, state, stats, descs, stat_scale, B);
 }

@@ -1,0 +1,313 @@
+// kernels_mfma.hip -- LDS-tiled, f32-MFMA kernels for the wide-channel convolutions of the multiscale VAE
+// (gfx950 / CDNA4: wave = 64 lanes, v_mfma_f32_32x32x2_f32 = exact fp32 at the vector rate, 160 KiB LDS / CU).
+//
+// Every conv on the hot path is a tall-skinny GEMM: M = B*H*W rows (10^5..10^6), N and K are 32 or 64 channels
+// (x taps).  One wave owns 32 rows x all N columns, the 32-row activation tile is staged through LDS with fully
+// coalesced 16-byte loads, the (tiny) weight matrix lives in LDS for the whole kernel, and everything that
+// the reference materialises as separate Keras layers around the matmul (bias, ReLU/ELU, squeeze-excite gate,
+// folded BatchNorm, residual add, bias gradient) is fused into the load / store of the tile.
+//
+// MFMA operand maps (cdna_hip_programming.md section 3):  v_mfma_f32_32x32x2_f32, lane l:
+//   A[i = l & 31][k = l >> 5],  B[k = l >> 5][j = l & 31],  D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]
+// The k index is a dummy summation index, so lane-half h = l >> 5 may take ANY half of the k range as long as the
+// A and B operands agree: here half h owns k in [h*K/2, (h+1)*K/2), which makes each lane's A fragment a
+// contiguous run of floats (16-byte LDS reads).
+#include "kernels.h"
+
+namespace mvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply_m(float v, int act) {
+  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
+  return v;
+}
+
+// =================================================================================================
+// Y[M,N] = act( pre(X)[M,K] . Wm[K,N] + bias ) + residual        (1x1 convolution, stride 1)
+//   WT = false: Wm[k][n] = W[k*N + n]   (Conv2D forward, kernel [1,1,CI=K,CO=N])
+//   WT = true : Wm[k][n] = W[n*K + k]   (its backward-data / Conv2DTranspose forward: kernel [1,1,CI=N,CO=K])
+// block = 4 waves; wave w owns rows [tile*128 + 32w, +32).  Persistent over tiles.
+// =================================================================================================
+template <int K, int N, bool WT>
+__global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, const float* __restrict__ residual,
+                                                   float* __restrict__ Y, int64_t M, int64_t rows_per_image, PreOp pre,
+                                                   int act) {
+  constexpr int KH = K / 2;          // k's per lane half
+  constexpr int AST = K + 4;         // padded LDS row stride (floats): conflict-free ds_read_b128 fragments
+  constexpr int NT = N / 32;
+  constexpr int C4 = K / 4;          // float4 chunks per row
+  constexpr int LD = K / 8;          // float4 loads per lane per 32-row tile
+  __shared__ __attribute__((aligned(16))) float lds[K * N + 4 * 32 * AST];
+  float* sW = lds;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* sA = lds + K * N + wave * 32 * AST;
+  for (int idx = threadIdx.x; idx < K * N; idx += 256) {
+    int k = idx / N, n = idx % N;
+    sW[idx] = WT ? W[(int64_t)n * K + k] : W[idx];
+  }
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (M + 127) / 128;
+  const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
+
+  f32x4 stage[LD];
+  auto load_tile = [&](int64_t tile) {
+    const int64_t row0 = tile * 128 + wave * 32;
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+      int f = j * 64 + lane;
+      int r = f / C4, c4 = f % C4;
+      int64_t row = row0 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < M) {
+        v = X4[row * C4 + c4];
+        if (pre.scale) {
+          f32x4 sc = reinterpret_cast<const f32x4*>(pre.scale)[c4], sf = reinterpret_cast<const f32x4*>(pre.shift)[c4];
+          v = v * sc + sf;
+        }
+        if (pre.gate) {
+          int64_t b = row / rows_per_image;
+          v = v * reinterpret_cast<const f32x4*>(pre.gate)[b * C4 + c4];
+        }
+      }
+      stage[j] = v;
+    }
+  };
+
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();     // previous iteration's fragment reads are done (and sW is staged on the first pass)
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+      int f = j * 64 + lane;
+      int r = f / C4, c4 = f % C4;
+      *reinterpret_cast<f32x4*>(&sA[r * AST + c4 * 4]) = stage[j];
+    }
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);    // prefetch under the MFMAs
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+      f32x4 a4 = *reinterpret_cast<const f32x4*>(&sA[i * AST + h * KH + q * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = h * KH + q * 4 + e;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], sW[k * N + nt * 32 + i], acc[nt], 0, 0, 0);
+      }
+    }
+    const int64_t row0 = tile * 128 + wave * 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 32 + i;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) {
+          float v = act_apply_m(acc[nt][r] + bv, act);
+          if (residual) v += residual[row * N + n];
+          Y[row * N + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int K, int N, bool WT>
+static void run_gemm_rows(const float* X, const float* W, const float* bias, const float* residual, float* Y,
+                          int64_t M, int64_t rows_per_image, PreOp pre, int act, hipStream_t s) {
+  int64_t ntiles = (M + 127) / 128;
+  int grid = (int)(ntiles < 768 ? ntiles : 768);     // 256 CUs x 3 resident workgroups
+  hipLaunchKernelGGL((k_gemm_rows<K, N, WT>), dim3(grid), dim3(256), 0, s, X, W, bias, residual, Y, M, rows_per_image,
+                     pre, act);
+}
+
+// returns false when the shape is not covered (caller falls back to the generic kernel)
+bool launch_conv1x1_mfma(bool transposed, const float* in, const float* w, const float* bias, const float* residual,
+                         float* out, const ConvGeom& g, PreOp pre, int act, hipStream_t s) {
+  if (g.KH != 1 || g.KW != 1 || g.SH != 1 || g.SW != 1) return false;
+  const int K = transposed ? g.CO : g.CI, N = transposed ? g.CI : g.CO;
+  const int64_t M = (int64_t)g.B * g.IH * g.IW, rpi = (int64_t)g.IH * g.IW;
+#define MVAE_GR(KK, NN)                                                                                   \
+  if (K == KK && N == NN) {                                                                               \
+    if (transposed) run_gemm_rows<KK, NN, true>(in, w, bias, residual, out, M, rpi, pre, act, s);         \
+    else run_gemm_rows<KK, NN, false>(in, w, bias, residual, out, M, rpi, pre, act, s);                   \
+    return true;                                                                                          \
+  }
+  MVAE_GR(64, 64) MVAE_GR(32, 32) MVAE_GR(64, 32) MVAE_GR(32, 64)
+#undef MVAE_GR
+  return false;
+}
+
+// =================================================================================================
+// dW[tap][ci][co] += sum_m pre(big)[gather(m, tap)][ci] * small[m][co]   ;   db[co] += sum_m small[m][co]
+// (weight gradient of a strided SAME conv in F-form coordinates; 1x1 is the tap-less special case.)
+// grid = (row chunks, taps).  Wave w of a block takes every 4th 32-row tile of the chunk, accumulates a
+// CI x CO tile set in MFMA accumulators (D[i = ci][j = co]), the 4 waves are reduced through LDS and the block
+// issues ONE set of coalesced float atomics (256-byte segments).
+// =================================================================================================
+template <int CI, int CO>
+__global__ void __launch_bounds__(256) k_wgrad_rows(const float* __restrict__ big, const float* __restrict__ small,
+                                                    float* __restrict__ dW, float* __restrict__ db, ConvGeom g,
+                                                    PreOp pre, int64_t M, int64_t rows_per_block) {
+  constexpr int KT = CI / 32, NT = CO / 32;
+  constexpr int CI4 = CI / 4, CO4 = CO / 4;
+  __shared__ __attribute__((aligned(16))) float lds[4 * 32 * (CI + CO)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* sX = lds + wave * 32 * (CI + CO);
+  float* sG = sX + 32 * CI;
+  const int i = lane & 31, h = lane >> 5;
+  const int tap = blockIdx.y, kh = tap / g.KW, kw = tap % g.KW;
+  const f32x4* big4 = reinterpret_cast<const f32x4*>(big);
+  const f32x4* small4 = reinterpret_cast<const f32x4*>(small);
+  const bool pointwise = (g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1);
+
+  f32x16 acc[KT][NT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kt][nt][r] = 0.f;
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+
+  const int64_t m_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t m_end = m_begin + rows_per_block;
+  if (m_end > M) m_end = M;
+  const int64_t ntile = (m_end - m_begin + 127) / 128;     // block-uniform trip count
+  for (int64_t t = 0; t < ntile; ++t) {
+    const int64_t row0 = m_begin + t * 128 + wave * 32;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CI / 8; ++j) {
+      int f = j * 64 + lane;
+      int r = f / CI4, c4 = f % CI4;
+      int64_t m = row0 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) {
+        int64_t src = m;
+        int64_t b = 0;
+        bool ok = true;
+        if (!pointwise) {
+          int ow = (int)(m % g.OW);
+          int64_t p = m / g.OW;
+          int oh = (int)(p % g.OH);
+          b = p / g.OH;
+          int yy = oh * g.SH + kh - g.PT, xx = ow * g.SW + kw - g.PL;
+          ok = yy >= 0 && yy < g.IH && xx >= 0 && xx < g.IW;
+          src = (b * g.IH + yy) * g.IW + xx;
+        } else if (pre.gate) {
+          b = m / ((int64_t)g.IH * g.IW);
+        }
+        if (ok) {
+          v = big4[src * CI4 + c4];
+          if (pre.scale) {
+            f32x4 sc = reinterpret_cast<const f32x4*>(pre.scale)[c4], sf = reinterpret_cast<const f32x4*>(pre.shift)[c4];
+            v = v * sc + sf;
+          }
+          if (pre.gate) v = v * reinterpret_cast<const f32x4*>(pre.gate)[b * CI4 + c4];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&sX[r * CI + c4 * 4]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < CO / 8; ++j) {
+      int f = j * 64 + lane;
+      int r = f / CO4, c4 = f % CO4;
+      int64_t m = row0 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) v = small4[m * CO4 + c4];
+      *reinterpret_cast<f32x4*>(&sG[r * CO + c4 * 4]) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int tt = 0; tt < 16; ++tt) {
+      const int r = h * 16 + tt;          // lane half h sums rows [16h, 16h+16) of the tile
+      float a[KT], bq[NT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) a[kt] = sX[r * CI + kt * 32 + i];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { bq[nt] = sG[r * CO + nt * 32 + i]; bsum[nt] += bq[nt]; }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], bq[nt], acc[kt][nt], 0, 0, 0);
+    }
+  }
+  // ---- reduce the 4 waves through LDS (reuse the staging area: CI*CO <= 4*32*(CI+CO)/... checked by launcher)
+  __syncthreads();
+  float* red = lds;                  // [CI][CO]
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int ci = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            int idx = ci * CO + nt * 32 + i;
+            red[idx] = (wv == 0 ? 0.f : red[idx]) + acc[kt][nt][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* dWt = dW + (int64_t)tap * CI * CO;
+  for (int idx = threadIdx.x; idx < CI * CO; idx += 256) atomicAdd(&dWt[idx], red[idx]);
+  if (db != nullptr && tap == 0) {
+    __syncthreads();
+    float* rb = lds;                 // [8][CO]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) rb[(wave * 2 + h) * CO + nt * 32 + i] = bsum[nt];
+    __syncthreads();
+    if (threadIdx.x < CO) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += rb[q * CO + threadIdx.x];
+      atomicAdd(&db[threadIdx.x], t);
+    }
+  }
+}
+
+template <int CI, int CO>
+static void run_wgrad_rows(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, PreOp pre,
+                           hipStream_t s) {
+  const int64_t M = (int64_t)g.B * g.OH * g.OW;
+  const int taps = g.KH * g.KW;
+  // ~512 blocks in total keeps every CU busy (2 resident blocks) while bounding the float-atomic traffic
+  int64_t chunks = 512 / taps;
+  if (chunks < 1) chunks = 1;
+  int64_t rpb = (M + chunks - 1) / chunks;
+  rpb = (rpb + 127) / 128 * 128;
+  if (rpb < 128) rpb = 128;
+  chunks = (M + rpb - 1) / rpb;
+  hipLaunchKernelGGL((k_wgrad_rows<CI, CO>), dim3((unsigned)chunks, taps), dim3(256), 0, s, big, small, dW, db, g, pre,
+                     M, rpb);
+}
+
+bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, PreOp pre,
+                            hipStream_t s) {
+#define MVAE_WG(A, B_)                                                          \
+  if (g.CI == A && g.CO == B_) {                                                \
+    run_wgrad_rows<A, B_>(big, small, dW, db, g, pre, s);                       \
+    return true;                                                                \
+  }
+  MVAE_WG(64, 64) MVAE_WG(32, 32) MVAE_WG(64, 32) MVAE_WG(32, 64)
+#undef MVAE_WG
+  return false;
+}
+
+}  // namespace mvae

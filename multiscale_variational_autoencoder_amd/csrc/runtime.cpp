@@ -397,15 +397,14 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   const float* P = h->dp;
   float* G = h->dr;
   const int c = m.c;
-  const int64_t HW = (int64_t)m.H * m.W, M = HW * B;
+  const int64_t HW = (int64_t)m.H * m.W;
   ConvGeom g = geom1x1(B, m.H, m.W, c, c);
   PreOp none{nullptr, nullptr, nullptr};
   float* bufB = acquire(sc);
   launch_conv_t(dout, P + m.w2, nullptr, nullptr, bufB, g, s);                        // dt2 = dout . W2^T
   launch_spatial_dot(bufB, m.t1, sc.dg, B, HW, c, s);                                  // dg = sum_hw dt2 * t1
   PreOp gate{m.g, nullptr, nullptr};
-  launch_conv_wgrad(m.t1, dout, G + m.w2, g, gate, s);                                 // dW2 = (t1*g)^T dout
-  launch_colsum(dout, G + m.b2, M, c, s);
+  launch_conv_wgrad(m.t1, dout, G + m.w2, G + m.b2, g, gate, s);                       // dW2 = (t1*g)^T dout, db2
   // squeeze-excite backward
   launch_gemm_tn(m.xhat, sc.dg, G + m.sw1, G + m.sb1, B, c, c, P + m.gam, P + m.bet, m.ulin, s);
   launch_gemm_nt(sc.dg, P + m.sw1, sc.ds1, B, c, c, m.ulin, 0, s);
@@ -417,8 +416,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   launch_dw_wgrad(m.t0, bufB, G + m.wd, G + m.bd, B, m.H, m.W, c, s);
   float* bufC = acquire(sc);
   launch_dw_bwd_data(bufB, P + m.wd, m.t0, bufC, B, m.H, m.W, c, s);                   // dt0pre
-  launch_conv_wgrad(x, bufC, G + m.w0, g, none, s);
-  launch_colsum(bufC, G + m.b0, M, c, s);
+  launch_conv_wgrad(x, bufC, G + m.w0, G + m.b0, g, none, s);
   launch_conv_t(bufC, P + m.w0, nullptr, dout, bufB, g, s);                            // da = dt0pre.W0^T + dout
   release(sc, bufC);
   release(sc, dout);
@@ -673,8 +671,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     const float* xbn = sc.dec.back().mn.out;
     ConvGeom go = geom1x1(B, sc.H, sc.W, sc.dc, C);
     PreOp bn{nullptr, sc.bn_scale, sc.bn_shift};
-    launch_conv_wgrad(xbn, sc.dy, G + sc.out_w, go, bn, s);
-    launch_colsum(sc.dy, G + sc.out_b, M, C, s);
+    launch_conv_wgrad(xbn, sc.dy, G + sc.out_w, G + sc.out_b, go, bn, s);
     float* d = acquire(sc);
     launch_conv_t(sc.dy, P + sc.out_w, nullptr, nullptr, d, go, s);
     (void)hipMemsetAsync(sc.bn_sum_d, 0, sizeof(float) * sc.dc, s);
@@ -690,7 +687,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       d = mn_backward(h, sc, blk.mn, xin, d, B, s);
       if (blk.has_conv) {     // Conv2DTranspose: big = its output (d), small = its input (prev)
         ConvGeom g = blk.cg; g.B = B;
-        launch_conv_wgrad(d, prev, G + blk.cw, g, none, s);
+        launch_conv_wgrad(d, prev, G + blk.cw, nullptr, g, none, s);
         launch_colsum(d, G + blk.cb, (int64_t)B * g.IH * g.IW, g.CI, s);
         float* n = acquire(sc);
         launch_conv_f(d, P + blk.cw, nullptr, nullptr, n, g, none, ACT_NONE, s);
@@ -716,8 +713,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       d = mn_backward(h, sc, blk.mn, xin, d, B, s);
       if (blk.has_conv) {     // Conv2D: big = its input (prev), small = its output (d)
         ConvGeom g = blk.cg; g.B = B;
-        launch_conv_wgrad(prev, d, G + blk.cw, g, none, s);
-        launch_colsum(d, G + blk.cb, (int64_t)B * g.OH * g.OW, g.CO, s);
+        launch_conv_wgrad(prev, d, G + blk.cw, G + blk.cb, g, none, s);
         float* n = acquire(sc);
         launch_conv_t(d, P + blk.cw, nullptr, nullptr, n, g, s);
         release(sc, d);
@@ -729,8 +725,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     ConvGeom g{};
     g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
     g.KH = g.KW = 3; g.SH = g.SW = 1; g.PT = g.PL = 1;
-    launch_conv_wgrad(sc.band, d, G + sc.cb_w, g, none, s);
-    launch_colsum(d, G + sc.cb_b, M, kConvBaseFilters, s);
+    launch_conv_wgrad(sc.band, d, G + sc.cb_w, G + sc.cb_b, g, none, s);
     release(sc, d);
   }
   return check_launch(h, "mvae_backward");
