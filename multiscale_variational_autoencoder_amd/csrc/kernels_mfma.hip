@@ -310,4 +310,150 @@ bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, flo
   return false;
 }
 
+
+// =================================================================================================
+// k x k strided SAME convolution as a loop of per-tap rank-KC updates on the MFMA.
+//   TFORM = false (gather / F-form):  out = small[B,OH,OW,NC=CO],  in = big[B,IH,IW,KC=CI]
+//        small[p, n] = bias[n] + sum_tap sum_k big[b, oh*SH+kh-PT, ow*SW+kw-PL, k] * W[tap][k][n]
+//   TFORM = true  (transposed / T-form = conv backward-data = Conv2DTranspose forward):
+//        out = big[B,IH,IW,NC=CI],  in = small[B,OH,OW,KC=CO]
+//        big[b,y,x,n] = bias[n] + sum_{tap: (y+PT-kh) % SH == 0, ...} sum_k small[b,(y+PT-kh)/SH,(x+PL-kw)/SW,k] * W[tap][n][k]
+//     Output pixels are processed per sub-pixel phase (py,px) = (y % SH, x % SW) (blockIdx.y): all pixels of a phase
+//     share the same set of valid taps, so a wave never diverges (the "4 phase convs" of a stride-2 ConvT).
+// One wave = 32 output pixels x NC channels; per tap the lane's input pixel supplies a contiguous run of KC/2
+// channels straight from global memory (L2-resident re-reads across taps), the tap's KC x NC weight slice is
+// double-buffered in LDS for the whole block.
+// =================================================================================================
+template <int KC, int NC, bool TFORM>
+__global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
+  constexpr int KHF = KC / 2, NT = NC / 32, Q = KHF / 4;
+  __shared__ __attribute__((aligned(16))) float sW[2][KC * NC];
+  __shared__ int64_t sOff[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  // ---- which output pixels
+  int py = 0, px = 0, CH = g.OH, CW = g.OW;
+  if (TFORM) {
+    py = blockIdx.y / g.SW; px = blockIdx.y % g.SW;
+    CH = (g.IH - py + g.SH - 1) / g.SH; CW = (g.IW - px + g.SW - 1) / g.SW;
+  }
+  const int64_t Mc = (int64_t)g.B * CH * CW;
+  const int64_t p0 = (int64_t)blockIdx.x * 128;
+  if (p0 >= Mc) return;                         // block-uniform
+  const int64_t p = p0 + wave * 32 + i;
+  const bool pvalid = p < Mc;
+  int cx = 0, cy = 0;
+  int64_t b = 0;
+  if (pvalid) { cx = (int)(p % CW); int64_t q = p / CW; cy = (int)(q % CH); b = q / CH; }
+  if (h == 0) {
+    int64_t off = -1;
+    if (pvalid) off = TFORM ? (((b * g.IH + (cy * g.SH + py)) * g.IW + (cx * g.SW + px)) * NC) : p * NC;
+    sOff[wave][i] = off;
+  }
+  // ---- tap list (block-uniform)
+  int kh0 = 0, kw0 = 0, khs = 1, kws = 1;
+  if (TFORM) { kh0 = (py + g.PT) % g.SH; kw0 = (px + g.PL) % g.SW; khs = g.SH; kws = g.SW; }
+  const int nkh = kh0 < g.KH ? (g.KH - kh0 + khs - 1) / khs : 0;
+  const int nkw = kw0 < g.KW ? (g.KW - kw0 + kws - 1) / kws : 0;
+  const int ntaps = nkh * nkw;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+  auto stage_w = [&](int it, int buf) {
+    const int kh = kh0 + (it / nkw) * khs, kw = kw0 + (it % nkw) * kws;
+    const float* wt = W + (int64_t)(kh * g.KW + kw) * KC * NC;
+    for (int idx = threadIdx.x; idx < KC * NC; idx += 256) {
+      // sW[k][n]; F: W[tap][k][n] as stored; T: W[tap][n][k]
+      if (TFORM) { int n = idx / KC, k = idx % KC; sW[buf][k * NC + n] = wt[idx]; }
+      else sW[buf][idx] = wt[idx];
+    }
+  };
+  f32x4 a_next[Q];
+  auto load_a = [&](int it) {
+    const int kh = kh0 + (it / nkw) * khs, kw = kw0 + (it % nkw) * kws;
+    int yy, xx;
+    bool ok = pvalid;
+    if (TFORM) {
+      yy = cy + (py + g.PT - kh) / g.SH;          // exact: kh is in this phase's residue class
+      xx = cx + (px + g.PL - kw) / g.SW;
+      ok = ok && yy >= 0 && yy < g.OH && xx >= 0 && xx < g.OW;
+    } else {
+      yy = cy * g.SH + kh - g.PT;
+      xx = cx * g.SW + kw - g.PL;
+      ok = ok && yy >= 0 && yy < g.IH && xx >= 0 && xx < g.IW;
+    }
+    const int SHh = TFORM ? g.OH : g.IH, SWw = TFORM ? g.OW : g.IW;
+    const f32x4* src = reinterpret_cast<const f32x4*>(in + ((b * SHh + yy) * SWw + xx) * KC + h * KHF);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      a_next[q] = ok ? src[q] : z;
+    }
+  };
+
+  if (ntaps > 0) { stage_w(0, 0); load_a(0); }
+  for (int it = 0; it < ntaps; ++it) {
+    __syncthreads();
+    f32x4 a[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) a[q] = a_next[q];
+    if (it + 1 < ntaps) { stage_w(it + 1, (it + 1) & 1); load_a(it + 1); }
+    const float* w = sW[it & 1];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = h * KHF + q * 4 + e;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], w[k * NC + nt * 32 + i], acc[nt], 0, 0, 0);
+      }
+  }
+  __syncthreads();     // sOff visible (also when ntaps == 0)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 32 + i;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int64_t off = sOff[wave][(r & 3) + 8 * (r >> 2) + 4 * h];
+      if (off >= 0) out[off + n] = acc[nt][r] + bv;
+    }
+  }
+}
+
+template <int KC, int NC, bool TFORM>
+static void run_conv_taps(const float* in, const float* W, const float* bias, float* out, const ConvGeom& g,
+                          hipStream_t s) {
+  int64_t Mc;
+  int classes = 1;
+  if (TFORM) {
+    classes = g.SH * g.SW;
+    Mc = (int64_t)g.B * ((g.IH + g.SH - 1) / g.SH) * ((g.IW + g.SW - 1) / g.SW);   // largest phase
+  } else {
+    Mc = (int64_t)g.B * g.OH * g.OW;
+  }
+  hipLaunchKernelGGL((k_conv_taps<KC, NC, TFORM>), dim3((unsigned)((Mc + 127) / 128), classes), dim3(256), 0, s, in, W,
+                     bias, out, g);
+}
+
+bool launch_conv_taps_mfma(bool transposed, const float* in, const float* w, const float* bias, float* out,
+                           const ConvGeom& g, hipStream_t s) {
+  const int KC = transposed ? g.CO : g.CI, NC = transposed ? g.CI : g.CO;
+#define MVAE_CT(A, B_)                                                              \
+  if (KC == A && NC == B_) {                                                        \
+    if (transposed) run_conv_taps<A, B_, true>(in, w, bias, out, g, s);             \
+    else run_conv_taps<A, B_, false>(in, w, bias, out, g, s);                       \
+    return true;                                                                    \
+  }
+  MVAE_CT(32, 64) MVAE_CT(64, 32) MVAE_CT(32, 32) MVAE_CT(64, 64)
+#undef MVAE_CT
+  return false;
+}
+
 }  // namespace mvae
