@@ -2,6 +2,7 @@
 // the LDS/MFMA-tiled gfx950 kernels (kernels_mfma.hip).  Both are device paths; there is no CPU fallback.
 #include "kernels.h"
 #include "prof.h"
+#include <cstdio>
 
 namespace mvae {
 
@@ -11,6 +12,15 @@ Profiler& profiler() {
 }
 
 static inline double f4(double n) { return 4.0 * n; }
+// tag with the row count (log2 bucket) so the profile separates the big launches from the launch-bound ones
+static const char* tagm(const char* base, double rows) {
+  static thread_local char buf[64];
+  if (!profiler().on) return base;
+  int lg = 0;
+  while ((1ll << lg) < (long long)rows) ++lg;
+  snprintf(buf, sizeof(buf), "%s@2^%d", base, lg);
+  return buf;
+}
 
 void launch_conv_f_generic(const float*, const float*, const float*, const float*, float*, ConvGeom, PreOp, int,
                            hipStream_t);
@@ -43,7 +53,7 @@ bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, flo
 void launch_conv_f(const float* big, const float* w, const float* bias, const float* residual, float* small,
                    ConvGeom g, PreOp pre, int act, hipStream_t s) {
   double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
-  ProfScope ps(g.KH * g.KW == 1 ? "conv1x1_f" : "convkxk_f", f4(nb + ns * (residual ? 2 : 1) + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
+  ProfScope ps(tagm(g.KH * g.KW == 1 ? "conv1x1_f" : "convkxk_f", (double)g.B * g.OH * g.OW), f4(nb + ns * (residual ? 2 : 1) + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
   if (launch_conv1x1_mfma(false, big, w, bias, residual, small, g, pre, act, s)) return;
   if (g.KH * g.KW > 1 && !residual && !pre.gate && !pre.scale && act == ACT_NONE &&
       launch_conv_taps_mfma(false, big, w, bias, small, g, s)) return;
@@ -52,7 +62,7 @@ void launch_conv_f(const float* big, const float* w, const float* bias, const fl
 void launch_conv_t(const float* small, const float* w, const float* bias, const float* residual, float* big,
                    ConvGeom g, hipStream_t s) {
   double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
-  ProfScope ps(g.KH * g.KW == 1 ? "conv1x1_t" : "convkxk_t", f4(ns + nb * (residual ? 2 : 1) + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
+  ProfScope ps(tagm(g.KH * g.KW == 1 ? "conv1x1_t" : "convkxk_t", (double)g.B * g.IH * g.IW), f4(ns + nb * (residual ? 2 : 1) + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
   PreOp none{nullptr, nullptr, nullptr};
   if (launch_conv1x1_mfma(true, small, w, bias, residual, big, g, none, ACT_NONE, s)) return;
   if (g.KH * g.KW > 1 && !residual && launch_conv_taps_mfma(true, small, w, bias, big, g, s)) return;
@@ -61,7 +71,7 @@ void launch_conv_t(const float* small, const float* w, const float* bias, const 
 void launch_conv_wgrad(const float* big, const float* small, float* dW, float* db, ConvGeom g, PreOp pre,
                        hipStream_t s) {
   double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
-  ProfScope ps(g.KH * g.KW == 1 ? "conv1x1_wgrad" : "convkxk_wgrad", f4(nb + ns + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
+  ProfScope ps(tagm(g.KH * g.KW == 1 ? "conv1x1_wgrad" : "convkxk_wgrad", (double)g.B * g.OH * g.OW), f4(nb + ns + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
   if (launch_conv_wgrad_mfma(big, small, dW, db, g, pre, s)) return;
   launch_conv_wgrad_generic(big, small, dW, g, pre, s);
   if (db) launch_colsum(small, db, (int64_t)g.B * g.OH * g.OW, g.CO, s);
@@ -69,45 +79,45 @@ void launch_conv_wgrad(const float* big, const float* small, float* dW, float* d
 void launch_dw_fwd(const float* in, const float* w, const float* b, float* out, int B, int H, int W, int C,
                    hipStream_t s) {
   double n = (double)B * H * W * C;
-  ProfScope ps("dw_fwd", f4(2 * n), 18.0 * n, s);
+  ProfScope ps(tagm("dw_fwd", n), f4(2 * n), 18.0 * n, s);
   if (launch_dw_fwd_opt(in, w, b, out, B, H, W, C, s)) return;
   launch_dw_fwd_generic(in, w, b, out, B, H, W, C, s);
 }
 void launch_dw_bwd_data(const float* dy, const float* w, const float* mask_src, float* dx, int B, int H, int W,
                         int C, hipStream_t s) {
   double n = (double)B * H * W * C;
-  ProfScope ps("dw_bwd_data", f4(3 * n), 18.0 * n, s);
+  ProfScope ps(tagm("dw_bwd_data", n), f4(3 * n), 18.0 * n, s);
   if (launch_dw_bwd_data_opt(dy, w, mask_src, dx, B, H, W, C, s)) return;
   launch_dw_bwd_data_generic(dy, w, mask_src, dx, B, H, W, C, s);
 }
 void launch_dw_wgrad(const float* in, const float* dy, float* dW, float* db, int B, int H, int W, int C,
                      hipStream_t s) {
   double n = (double)B * H * W * C;
-  ProfScope ps("dw_wgrad", f4(2 * n), 20.0 * n, s);
+  ProfScope ps(tagm("dw_wgrad", n), f4(2 * n), 20.0 * n, s);
   if (launch_dw_wgrad_opt(in, dy, dW, db, B, H, W, C, s)) return;
   launch_dw_wgrad_generic(in, dy, dW, db, B, H, W, C, s);
 }
 void launch_mn_dt1pre(float* d, const float* t1, const float* g, const float* dgap, int B, int64_t HW, int C,
                       float inv_hw, hipStream_t s) {
   double n = (double)B * HW * C;
-  ProfScope ps("mn_dt1pre", f4(3 * n), 3.0 * n, s);
+  ProfScope ps(tagm("mn_dt1pre", n), f4(3 * n), 3.0 * n, s);
   launch_mn_dt1pre_generic(d, t1, g, dgap, B, HW, C, inv_hw, s);
 }
 void launch_gemm_nn(const float* a, const float* w, const float* bias, float* out, float* out_lin, int B, int K,
                     int N, int act, hipStream_t s) {
-  ProfScope ps("gemm_nn", f4((double)B * K + (double)K * N + (double)B * N), 2.0 * B * K * N, s);
+  ProfScope ps(tagm("gemm_nn", (double)K * N), f4((double)B * K + (double)K * N + (double)B * N), 2.0 * B * K * N, s);
   if (launch_gemm_nn_opt(a, w, bias, out, out_lin, B, K, N, act, s)) return;
   launch_gemm_nn_generic(a, w, bias, out, out_lin, B, K, N, act, s);
 }
 void launch_gemm_nt(const float* a, const float* w, float* out, int B, int K, int N, const float* hs_lin,
                     int accumulate, hipStream_t s) {
-  ProfScope ps("gemm_nt", f4((double)B * K + (double)K * N + (double)B * N), 2.0 * B * K * N, s);
+  ProfScope ps(tagm("gemm_nt", (double)K * N), f4((double)B * K + (double)K * N + (double)B * N), 2.0 * B * K * N, s);
   if (launch_gemm_nt_opt(a, w, out, B, K, N, hs_lin, accumulate, s)) return;
   launch_gemm_nt_generic(a, w, out, B, K, N, hs_lin, accumulate, s);
 }
 void launch_gemm_tn(const float* a, const float* g, float* dW, float* db, int B, int K, int N, const float* a_scale,
                     const float* a_shift, const float* hs_lin, hipStream_t s) {
-  ProfScope ps("gemm_tn", f4((double)B * K + (double)K * N + (double)B * N), 2.0 * B * K * N, s);
+  ProfScope ps(tagm("gemm_tn", (double)K * N), f4((double)B * K + (double)K * N + (double)B * N), 2.0 * B * K * N, s);
   if (launch_gemm_tn_opt(a, g, dW, db, B, K, N, a_scale, a_shift, hs_lin, s)) return;
   launch_gemm_tn_generic(a, g, dW, db, B, K, N, a_scale, a_shift, hs_lin, s);
 }

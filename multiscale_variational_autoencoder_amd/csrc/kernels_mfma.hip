@@ -19,6 +19,15 @@ namespace mvae {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// A wave's LDS instructions execute in issue order, so data one lane wrote is visible to a later ds_read of any
+// lane of the SAME wave; only the compiler has to be kept from reordering across the hand-off.
+#define WAVE_LDS_SYNC()                                      \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
 __device__ __forceinline__ float act_apply_m(float v, int act) {
   if (act == ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
@@ -36,42 +45,43 @@ __global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, 
                                                    const float* __restrict__ bias, const float* __restrict__ residual,
                                                    float* __restrict__ Y, int64_t M, int64_t rows_per_image, PreOp pre,
                                                    int act) {
-  constexpr int KH = K / 2;          // k's per lane half
-  constexpr int AST = K + 4;         // padded LDS row stride (floats): conflict-free ds_read_b128 fragments
+  constexpr int KH = K / 2;                    // k's per lane half
+  constexpr int TS = (K > N ? K : N) + 4;      // padded LDS row stride (floats) of the A tile and of the C tile
   constexpr int NT = N / 32;
-  constexpr int C4 = K / 4;          // float4 chunks per row
-  constexpr int LD = K / 8;          // float4 loads per lane per 32-row tile
-  __shared__ __attribute__((aligned(16))) float lds[K * N + 4 * 32 * AST];
+  constexpr int C4 = K / 4, N4 = N / 4;        // float4 chunks per input / output row
+  constexpr int LD = K / 8, ST = N / 8;        // float4 loads / stores per lane per 32-row tile
+  constexpr int RPL = 64 / C4, RPS = 64 / N4;  // rows covered by one wave-wide float4 load / store
+  __shared__ __attribute__((aligned(16))) float lds[K * N + 4 * 32 * TS];
   float* sW = lds;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* sA = lds + K * N + wave * 32 * AST;
+  float* sT = lds + K * N + wave * 32 * TS;    // this wave's tile: A operand first, C result afterwards
   for (int idx = threadIdx.x; idx < K * N; idx += 256) {
     int k = idx / N, n = idx % N;
     sW[idx] = WT ? W[(int64_t)n * K + k] : W[idx];
   }
   const int i = lane & 31, h = lane >> 5;
+  const int lc4 = lane % C4, lr = lane / C4;   // load mapping: row = j*RPL + lr, chunk lc4
+  const int sc4 = lane % N4, sr = lane / N4;   // store mapping
   const int64_t ntiles = (M + 127) / 128;
   const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
+  const f32x4* R4 = reinterpret_cast<const f32x4*>(residual);
+  f32x4* Y4 = reinterpret_cast<f32x4*>(Y);
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bias4 = reinterpret_cast<const f32x4*>(bias)[sc4];
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  if (pre.scale) { psc = reinterpret_cast<const f32x4*>(pre.scale)[lc4]; psh = reinterpret_cast<const f32x4*>(pre.shift)[lc4]; }
 
   f32x4 stage[LD];
   auto load_tile = [&](int64_t tile) {
     const int64_t row0 = tile * 128 + wave * 32;
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
-      int f = j * 64 + lane;
-      int r = f / C4, c4 = f % C4;
-      int64_t row = row0 + r;
+      int64_t row = row0 + j * RPL + lr;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < M) {
-        v = X4[row * C4 + c4];
-        if (pre.scale) {
-          f32x4 sc = reinterpret_cast<const f32x4*>(pre.scale)[c4], sf = reinterpret_cast<const f32x4*>(pre.shift)[c4];
-          v = v * sc + sf;
-        }
-        if (pre.gate) {
-          int64_t b = row / rows_per_image;
-          v = v * reinterpret_cast<const f32x4*>(pre.gate)[b * C4 + c4];
-        }
+        v = X4[row * C4 + lc4];
+        if (pre.scale) v = v * psc + psh;
+        if (pre.gate) v = v * reinterpret_cast<const f32x4*>(pre.gate)[(row / rows_per_image) * C4 + lc4];
       }
       stage[j] = v;
     }
@@ -79,16 +89,23 @@ __global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, 
 
   int64_t tile = blockIdx.x;
   if (tile < ntiles) load_tile(tile);
+  __syncthreads();       // sW staged; everything below is wave-private (sT) or read-only (sW)
   for (; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();     // previous iteration's fragment reads are done (and sW is staged on the first pass)
+    const int64_t row0 = tile * 128 + wave * 32;
+    WAVE_LDS_SYNC();     // the previous tile's C read-back is done
 #pragma unroll
-    for (int j = 0; j < LD; ++j) {
-      int f = j * 64 + lane;
-      int r = f / C4, c4 = f % C4;
-      *reinterpret_cast<f32x4*>(&sA[r * AST + c4 * 4]) = stage[j];
-    }
-    __syncthreads();
+    for (int j = 0; j < LD; ++j) *reinterpret_cast<f32x4*>(&sT[(j * RPL + lr) * TS + lc4 * 4]) = stage[j];
+    WAVE_LDS_SYNC();
     if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);    // prefetch under the MFMAs
+    f32x4 res[ST];
+    if (residual) {
+#pragma unroll
+      for (int j = 0; j < ST; ++j) {
+        int64_t row = row0 + j * RPS + sr;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        res[j] = row < M ? R4[row * N4 + sc4] : z;
+      }
+    }
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -96,7 +113,7 @@ __global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, 
       for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q) {
-      f32x4 a4 = *reinterpret_cast<const f32x4*>(&sA[i * AST + h * KH + q * 4]);
+      f32x4 a4 = *reinterpret_cast<const f32x4*>(&sT[i * TS + h * KH + q * 4]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k = h * KH + q * 4 + e;
@@ -105,20 +122,23 @@ __global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, 
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], sW[k * N + nt * 32 + i], acc[nt], 0, 0, 0);
       }
     }
-    const int64_t row0 = tile * 128 + wave * 32;
+    WAVE_LDS_SYNC();     // every lane's A fragments are consumed: the tile buffer becomes the C tile
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 32 + i;
-      const float bv = bias ? bias[n] : 0.f;
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < M) {
-          float v = act_apply_m(acc[nt][r] + bv, act);
-          if (residual) v += residual[row * N + n];
-          Y[row * N + n] = v;
-        }
+      for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + nt * 32 + i] = acc[nt][r];
+    WAVE_LDS_SYNC();
+#pragma unroll
+    for (int j = 0; j < ST; ++j) {
+      const int r = j * RPS + sr;
+      int64_t row = row0 + r;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&sT[r * TS + sc4 * 4]) + bias4;
+      if (act != ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply_m(v[e], act);
       }
+      if (residual) v = v + res[j];
+      if (row < M) Y4[row * N4 + sc4] = v;
     }
   }
 }
@@ -157,20 +177,28 @@ bool launch_conv1x1_mfma(bool transposed, const float* in, const float* w, const
 // issues ONE set of coalesced float atomics (256-byte segments).
 // =================================================================================================
 template <int CI, int CO>
-__global__ void __launch_bounds__(256) k_wgrad_rows(const float* __restrict__ big, const float* __restrict__ small,
-                                                    float* __restrict__ dW, float* __restrict__ db, ConvGeom g,
-                                                    PreOp pre, int64_t M, int64_t rows_per_block) {
+__global__ void __launch_bounds__(256, 3) k_wgrad_rows(const float* __restrict__ big, const float* __restrict__ small,
+                                                       float* __restrict__ dW, float* __restrict__ db, ConvGeom g,
+                                                       PreOp pre, int64_t M, int64_t rows_per_block) {
   constexpr int KT = CI / 32, NT = CO / 32;
+  constexpr int R = 16;                          // rows per wave tile
   constexpr int CI4 = CI / 4, CO4 = CO / 4;
-  __shared__ __attribute__((aligned(16))) float lds[4 * 32 * (CI + CO)];
+  constexpr int LX = R * CI4 / 64, LG = R * CO4 / 64;       // float4 loads per lane per tile
+  constexpr int RPX = 64 / CI4, RPG = 64 / CO4;             // rows covered by one wave-wide float4 load
+  constexpr int TILE = R * (CI + CO);
+  __shared__ __attribute__((aligned(16))) float lds[(4 * TILE > CI * CO) ? 4 * TILE : CI * CO];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* sX = lds + wave * 32 * (CI + CO);
-  float* sG = sX + 32 * CI;
+  float* sX = lds + wave * TILE;
+  float* sG = sX + R * CI;
   const int i = lane & 31, h = lane >> 5;
   const int tap = blockIdx.y, kh = tap / g.KW, kw = tap % g.KW;
+  const bool pointwise = (g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1);
+  const int64_t HWo = (int64_t)g.OH * g.OW;
   const f32x4* big4 = reinterpret_cast<const f32x4*>(big);
   const f32x4* small4 = reinterpret_cast<const f32x4*>(small);
-  const bool pointwise = (g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1);
+  const int xc4 = lane % CI4, xr = lane / CI4, gc4 = lane % CO4, gr = lane / CO4;
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  if (pre.scale) { psc = reinterpret_cast<const f32x4*>(pre.scale)[xc4]; psh = reinterpret_cast<const f32x4*>(pre.shift)[xc4]; }
 
   f32x16 acc[KT][NT];
 #pragma unroll
@@ -186,55 +214,55 @@ __global__ void __launch_bounds__(256) k_wgrad_rows(const float* __restrict__ bi
   const int64_t m_begin = (int64_t)blockIdx.x * rows_per_block;
   int64_t m_end = m_begin + rows_per_block;
   if (m_end > M) m_end = M;
-  const int64_t ntile = (m_end - m_begin + 127) / 128;     // block-uniform trip count
-  for (int64_t t = 0; t < ntile; ++t) {
-    const int64_t row0 = m_begin + t * 128 + wave * 32;
-    __syncthreads();
+
+  f32x4 px[LX], pg[LG];
+  auto load_tile = [&](int64_t row0) {
+    // decode this lane's first row once, then step RPX rows per load
+    int64_t m = row0 + xr;
+    int64_t b = m / HWo;
+    int rem = (int)(m - b * HWo);
+    int oh = rem / g.OW, ow = rem - oh * g.OW;
 #pragma unroll
-    for (int j = 0; j < CI / 8; ++j) {
-      int f = j * 64 + lane;
-      int r = f / CI4, c4 = f % CI4;
-      int64_t m = row0 + r;
+    for (int j = 0; j < LX; ++j) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end) {
-        int64_t src = m;
-        int64_t b = 0;
-        bool ok = true;
-        if (!pointwise) {
-          int ow = (int)(m % g.OW);
-          int64_t p = m / g.OW;
-          int oh = (int)(p % g.OH);
-          b = p / g.OH;
-          int yy = oh * g.SH + kh - g.PT, xx = ow * g.SW + kw - g.PL;
-          ok = yy >= 0 && yy < g.IH && xx >= 0 && xx < g.IW;
-          src = (b * g.IH + yy) * g.IW + xx;
-        } else if (pre.gate) {
-          b = m / ((int64_t)g.IH * g.IW);
-        }
-        if (ok) {
-          v = big4[src * CI4 + c4];
-          if (pre.scale) {
-            f32x4 sc = reinterpret_cast<const f32x4*>(pre.scale)[c4], sf = reinterpret_cast<const f32x4*>(pre.shift)[c4];
-            v = v * sc + sf;
-          }
-          if (pre.gate) v = v * reinterpret_cast<const f32x4*>(pre.gate)[b * CI4 + c4];
-        }
+      bool ok = m < m_end;
+      int64_t src = m;
+      if (!pointwise) {
+        const int yy = oh * g.SH + kh - g.PT, xx = ow * g.SW + kw - g.PL;
+        ok = ok && yy >= 0 && yy < g.IH && xx >= 0 && xx < g.IW;
+        src = (b * g.IH + yy) * g.IW + xx;
       }
-      *reinterpret_cast<f32x4*>(&sX[r * CI + c4 * 4]) = v;
+      if (ok) {
+        v = big4[src * CI4 + xc4];
+        if (pre.scale) v = v * psc + psh;
+        if (pre.gate) v = v * reinterpret_cast<const f32x4*>(pre.gate)[b * CI4 + xc4];
+      }
+      px[j] = v;
+      m += RPX;
+      ow += RPX;
+      while (ow >= g.OW) { ow -= g.OW; if (++oh == g.OH) { oh = 0; ++b; } }
     }
 #pragma unroll
-    for (int j = 0; j < CO / 8; ++j) {
-      int f = j * 64 + lane;
-      int r = f / CO4, c4 = f % CO4;
-      int64_t m = row0 + r;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end) v = small4[m * CO4 + c4];
-      *reinterpret_cast<f32x4*>(&sG[r * CO + c4 * 4]) = v;
+    for (int j = 0; j < LG; ++j) {
+      int64_t mm = row0 + j * RPG + gr;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      pg[j] = mm < m_end ? small4[mm * CO4 + gc4] : z;
     }
-    __syncthreads();
-#pragma unroll 4
-    for (int tt = 0; tt < 16; ++tt) {
-      const int r = h * 16 + tt;          // lane half h sums rows [16h, 16h+16) of the tile
+  };
+
+  int64_t row0 = m_begin + wave * R;
+  if (row0 < m_end) load_tile(row0);
+  for (; row0 < m_end; row0 += 4 * R) {
+    WAVE_LDS_SYNC();       // the previous tile's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < LX; ++j) *reinterpret_cast<f32x4*>(&sX[(j * RPX + xr) * CI + xc4 * 4]) = px[j];
+#pragma unroll
+    for (int j = 0; j < LG; ++j) *reinterpret_cast<f32x4*>(&sG[(j * RPG + gr) * CO + gc4 * 4]) = pg[j];
+    WAVE_LDS_SYNC();
+    if (row0 + 4 * R < m_end) load_tile(row0 + 4 * R);       // prefetch under the MFMAs
+#pragma unroll
+    for (int tt = 0; tt < R / 2; ++tt) {
+      const int r = h * (R / 2) + tt;       // lane half h sums rows [8h, 8h+8) of the tile
       float a[KT], bq[NT];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) a[kt] = sX[r * CI + kt * 32 + i];
@@ -247,9 +275,9 @@ __global__ void __launch_bounds__(256) k_wgrad_rows(const float* __restrict__ bi
           acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], bq[nt], acc[kt][nt], 0, 0, 0);
     }
   }
-  // ---- reduce the 4 waves through LDS (reuse the staging area: CI*CO <= 4*32*(CI+CO)/... checked by launcher)
+  // ---- reduce the 4 waves through LDS, then ONE set of coalesced float atomics per block
   __syncthreads();
-  float* red = lds;                  // [CI][CO]
+  float* red = lds;
   for (int wv = 0; wv < 4; ++wv) {
     if (wave == wv) {
 #pragma unroll
@@ -269,14 +297,13 @@ __global__ void __launch_bounds__(256) k_wgrad_rows(const float* __restrict__ bi
   for (int idx = threadIdx.x; idx < CI * CO; idx += 256) atomicAdd(&dWt[idx], red[idx]);
   if (db != nullptr && tap == 0) {
     __syncthreads();
-    float* rb = lds;                 // [8][CO]
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) rb[(wave * 2 + h) * CO + nt * 32 + i] = bsum[nt];
+    for (int nt = 0; nt < NT; ++nt) red[(wave * 2 + h) * CO + nt * 32 + i] = bsum[nt];
     __syncthreads();
     if (threadIdx.x < CO) {
       float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) t += rb[q * CO + threadIdx.x];
+      for (int q = 0; q < 8; ++q) t += red[q * CO + threadIdx.x];
       atomicAdd(&db[threadIdx.x], t);
     }
   }
@@ -287,12 +314,12 @@ static void run_wgrad_rows(const float* big, const float* small, float* dW, floa
                            hipStream_t s) {
   const int64_t M = (int64_t)g.B * g.OH * g.OW;
   const int taps = g.KH * g.KW;
-  // ~512 blocks in total keeps every CU busy (2 resident blocks) while bounding the float-atomic traffic
-  int64_t chunks = 512 / taps;
+  // ~768 blocks in total keeps every CU busy (3 resident blocks) while bounding the float-atomic traffic
+  int64_t chunks = 768 / taps;
   if (chunks < 1) chunks = 1;
   int64_t rpb = (M + chunks - 1) / chunks;
-  rpb = (rpb + 127) / 128 * 128;
-  if (rpb < 128) rpb = 128;
+  rpb = (rpb + 63) / 64 * 64;
+  if (rpb < 64) rpb = 64;
   chunks = (M + rpb - 1) / rpb;
   hipLaunchKernelGGL((k_wgrad_rows<CI, CO>), dim3((unsigned)chunks, taps), dim3(256), 0, s, big, small, dW, db, g, pre,
                      M, rpb);
