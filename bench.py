@@ -123,7 +123,7 @@ def main():
     def step(i):
         eng.train_step(x, lr, rf, kf, clip, seed=1000 + i)
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 1)):     # the first call of each signature captures its hipGraph
         step(i)
     torch.cuda.synchronize()
     if world > 1:

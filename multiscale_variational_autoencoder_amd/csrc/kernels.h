@@ -23,8 +23,11 @@ struct PreOp {               // transform applied to the BIG-side operand when i
 };
 
 // ---- RNG (Philox4x32-10) ----
-void launch_rng_normal(float* out, int64_t n, float stddev, uint64_t seed, uint32_t stream_id, hipStream_t s);
-void launch_rng_keepmask(float* out, int64_t n, float p_drop, uint64_t seed, uint32_t stream_id, hipStream_t s);
+// the seed is read from DEVICE memory so that a captured hipGraph stays valid from step to step
+void launch_set_u64(uint64_t* dst, uint64_t v, hipStream_t s);
+void launch_zero(float* p, int64_t n, hipStream_t s);
+void launch_rng_normal(float* out, int64_t n, float stddev, const uint64_t* seed, uint32_t stream_id, hipStream_t s);
+void launch_rng_keepmask(float* out, int64_t n, float p_drop, const uint64_t* seed, uint32_t stream_id, hipStream_t s);
 
 // ---- input transform (multiscale_vae.py:129-160, 292-315) ----
 void launch_prep(const float* x, const float* noise, const float* keep, float* out, int B, int H, int W, int C,

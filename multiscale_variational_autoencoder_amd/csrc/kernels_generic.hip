@@ -68,7 +68,8 @@ __device__ __forceinline__ U4 philox(uint64_t ctr, uint32_t stream_id, uint64_t 
 }
 __device__ __forceinline__ float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
-__global__ void k_rng_normal(float* out, int64_t n, float stddev, uint64_t seed, uint32_t sid) {
+__global__ void k_rng_normal(float* out, int64_t n, float stddev, const uint64_t* seed_ptr, uint32_t sid) {
+  const uint64_t seed = *seed_ptr;
   int64_t n4 = (n + 3) / 4;
   GRID_STRIDE(i, n4) {
     U4 r = philox((uint64_t)i, sid, seed);
@@ -79,7 +80,8 @@ __global__ void k_rng_normal(float* out, int64_t n, float stddev, uint64_t seed,
       if (i * 4 + j < n) out[i * 4 + j] = v[j] * stddev;
   }
 }
-__global__ void k_rng_keepmask(float* out, int64_t n, float p_drop, uint64_t seed, uint32_t sid) {
+__global__ void k_rng_keepmask(float* out, int64_t n, float p_drop, const uint64_t* seed_ptr, uint32_t sid) {
+  const uint64_t seed = *seed_ptr;
   int64_t n4 = (n + 3) / 4;
   GRID_STRIDE(i, n4) {
     U4 r = philox((uint64_t)i, sid, seed);
@@ -88,12 +90,23 @@ __global__ void k_rng_keepmask(float* out, int64_t n, float p_drop, uint64_t see
       if (i * 4 + j < n) out[i * 4 + j] = u01(v[j]) >= p_drop ? 1.f : 0.f;
   }
 }
-void launch_rng_normal(float* out, int64_t n, float stddev, uint64_t seed, uint32_t sid, hipStream_t s) {
+void launch_rng_normal(float* out, int64_t n, float stddev, const uint64_t* seed, uint32_t sid, hipStream_t s) {
   ProfScope ps("rng", (double)(4.0*n), 0.0, s);
   if (n <= 0) return;
   hipLaunchKernelGGL(k_rng_normal, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, s, out, n, stddev, seed, sid);
 }
-void launch_rng_keepmask(float* out, int64_t n, float p_drop, uint64_t seed, uint32_t sid, hipStream_t s) {
+// zero fill as a KERNEL: hipMemsetAsync nodes inside a captured hipGraph were observed to lose their ordering
+// against neighbouring kernel nodes on replay (ROCm 7.2), a kernel node keeps plain kernel->kernel edges.
+__global__ void k_zero(float* p, int64_t n) {
+  GRID_STRIDE(i, n) p[i] = 0.f;
+}
+void launch_zero(float* p, int64_t n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_zero, dim3(grid_for(n)), dim3(kBlock), 0, s, p, n);
+}
+__global__ void k_set_u64(uint64_t* dst, uint64_t v) { *dst = v; }
+void launch_set_u64(uint64_t* dst, uint64_t v, hipStream_t s) { hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, s, dst, v); }
+void launch_rng_keepmask(float* out, int64_t n, float p_drop, const uint64_t* seed, uint32_t sid, hipStream_t s) {
   ProfScope ps("rng", (double)(4.0*n), 0.0, s);
   if (n <= 0) return;
   hipLaunchKernelGGL(k_rng_keepmask, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, s, out, n, p_drop, seed, sid);
@@ -491,7 +504,7 @@ static void launch_spatial(const float* a, const float* b, float* out, int B, in
   int cpb = C < 256 ? C : 256;
   int64_t ppb = 4096;
   int64_t chunks = (HW + ppb - 1) / ppb;
-  if (chunks > 1) (void)hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), s);
+  if (chunks > 1) launch_zero(out, (int64_t)B * C, s);
   hipLaunchKernelGGL(k_spatial<MODE>, dim3((unsigned)chunks, (C + cpb - 1) / cpb, B), dim3(256), 0, s, a, b, out, HW,
                      C, cpb, scale, ppb, chunks > 1 ? 1 : 0);
 }

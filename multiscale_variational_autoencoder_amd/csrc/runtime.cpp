@@ -11,7 +11,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -91,6 +93,14 @@ struct mvae_handle {
   float* d_norms = nullptr;
   float *xin = nullptr, *eps_buf = nullptr, *noise_buf = nullptr, *keep_buf = nullptr, *recon = nullptr,
         *losses = nullptr, *sgn = nullptr, *reg_tmp = nullptr;
+  uint64_t* d_seed = nullptr;
+  int64_t off_seed = 0;
+  // concurrency: scale 0 runs on the caller's stream, every other scale on its own side stream (fork/join with
+  // events); each ABI call is captured into a hipGraph per argument signature and replayed.
+  bool multi_stream = true, use_graphs = true;
+  hipStream_t side[MVAE_MAX_LEVELS] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[MVAE_MAX_LEVELS] = {};
+  std::map<std::string, hipGraphExec_t> graphs;
   // last forward
   int last_B = 0, last_train_B = 0;
   bool last_training = false;
@@ -295,7 +305,7 @@ int build_plan(mvae_handle* h) {
   h->MET = align_up(4 + L);
   // global buffers
   int64_t hwC = (int64_t)c.input_h * c.input_w * C;
-  h->xin = nullptr;
+  h->xin = as_ptr(b.act("xin", hwC));
   h->eps_buf = as_ptr(b.act("eps", h->Z));
   h->noise_buf = as_ptr(b.act("noise", hwC));
   h->keep_buf = as_ptr(b.act("keep_mask", C));
@@ -324,6 +334,7 @@ int build_plan(mvae_handle* h) {
   h->off_chunks = b.ws_alloc((int64_t)(h->chunks.size() * sizeof(ChunkDesc) + 3) / 4);
   h->off_sdescs = b.ws_alloc((int64_t)(h->sdescs.size() * sizeof(StateDesc) + 3) / 4);
   h->off_norms = b.ws_alloc((int64_t)h->params.size());
+  h->off_seed = b.ws_alloc(kAlign);
   h->ws_floats = b.wcur;
   return MVAE_OK;
 }
@@ -350,6 +361,8 @@ void rebase_all(mvae_handle* h) {
     for (int k = 0; k < 4; ++k) rb(sc.scratch[k]);
     rb(sc.dg); rb(sc.dgap); rb(sc.ds1); rb(sc.dv); rb(sc.dz); rb(sc.dmu); rb(sc.dlv);
   }
+  rb(h->xin);
+  h->d_seed = reinterpret_cast<uint64_t*>(base + h->off_seed);
   rb(h->eps_buf); rb(h->noise_buf); rb(h->keep_buf); rb(h->recon); rb(h->losses); rb(h->sgn); rb(h->reg_tmp);
   h->d_chunks = reinterpret_cast<ChunkDesc*>(base + h->off_chunks);
   h->d_sdescs = reinterpret_cast<StateDesc*>(base + h->off_sdescs);
@@ -439,8 +452,8 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
   }
   const int64_t M = (int64_t)B * sc.H * sc.W;
   if (training) {
-    (void)hipMemsetAsync(sc.bn_sum, 0, sizeof(float) * sc.dc, s);
-    (void)hipMemsetAsync(sc.bn_sqdev, 0, sizeof(float) * sc.dc, s);
+    launch_zero(sc.bn_sum, (int64_t)(sc.dc), s);
+    launch_zero(sc.bn_sqdev, (int64_t)(sc.dc), s);
     launch_colsum(x, sc.bn_sum, M, sc.dc, s);
     launch_bn2d_mean(sc.bn_sum, nullptr, sc.bn_mean, M, sc.dc, 1, s);
     launch_colsqdev(x, sc.bn_mean, sc.bn_sqdev, M, sc.dc, s);
@@ -463,6 +476,56 @@ void merge_forward(mvae_handle* h, int B, float* recon, hipStream_t s) {
     launch_upsample_add(h->scales[i + 1].merged, sc.y, sc.merged, i == 0 ? recon : nullptr, B, sc.H, sc.W, sc.C,
                         c.min_value, c.max_value, s);
   }
+}
+
+// ---- fork / join of the per-scale chains over the side streams ------------------------------
+hipStream_t scale_stream(mvae_handle* h, int scale, hipStream_t main) {
+  return (h->multi_stream && scale > 0 && !profiler().on) ? h->side[scale] : main;
+}
+void fork_scales(mvae_handle* h, hipStream_t main) {
+  if (!h->multi_stream || profiler().on) return;
+  (void)hipEventRecord(h->ev_fork, main);
+  for (int l = 1; l < h->cfg.levels; ++l) (void)hipStreamWaitEvent(h->side[l], h->ev_fork, 0);
+}
+void join_scales(mvae_handle* h, hipStream_t main) {
+  if (!h->multi_stream || profiler().on) return;
+  for (int l = 1; l < h->cfg.levels; ++l) {
+    (void)hipEventRecord(h->ev_join[l], h->side[l]);
+    (void)hipStreamWaitEvent(main, h->ev_join[l], 0);
+  }
+}
+
+// ---- hipGraph cache: capture the launch sequence of one ABI call once per argument signature, then replay ----
+int run_captured(mvae_handle* h, const std::string& key, hipStream_t s, const std::function<void(hipStream_t)>& body) {
+  const bool eligible = h->use_graphs && !profiler().on && s != nullptr;
+  if (!eligible) { body(s); return MVAE_OK; }
+  auto it = h->graphs.find(key);
+  if (it == h->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      body(s);                        // e.g. the legacy default stream cannot be captured: run eagerly
+      return MVAE_OK;
+    }
+    body(s);
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(h, MVAE_E_HIP, "graph capture (%s): %s", key.c_str(), hipGetErrorString(e));
+    it = h->graphs.emplace(key, exec).first;
+  }
+  hipError_t e = hipGraphLaunch(it->second, s);
+  if (e != hipSuccess) return fail(h, MVAE_E_HIP, "hipGraphLaunch: %s", hipGetErrorString(e));
+  return MVAE_OK;
+}
+std::string fkey(const char* fmt, ...) {
+  char buf[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return buf;
 }
 
 int check_launch(mvae_handle* h, const char* what) {
@@ -516,7 +579,19 @@ int mvae_create(const mvae_config* cfg, mvae_handle** out) {
   return MVAE_OK;
 }
 
-void mvae_destroy(mvae_handle* h) { delete h; }
+void mvae_destroy(mvae_handle* h) {
+  if (!h) return;
+  if (h->bound) {
+    (void)hipDeviceSynchronize();
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (int l = 1; l < h->cfg.levels; ++l) {
+      if (h->side[l]) (void)hipStreamDestroy(h->side[l]);
+      if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  }
+  delete h;
+}
 
 int64_t mvae_param_count(const mvae_handle* h) { return h ? (int64_t)h->params.size() : -1; }
 int64_t mvae_param_elems(const mvae_handle* h) { return h ? h->P : -1; }
@@ -574,7 +649,14 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   float gf[9];
   for (int i = 0; i < 9; ++i) gf[i] = (float)(gk[i] / sum);
   set_gauss_constants(gf);
-  e = hipDeviceSynchronize();
+  if (const char* v = getenv("MVAE_GRAPHS")) h->use_graphs = atoi(v) != 0;
+  if (const char* v = getenv("MVAE_STREAMS")) h->multi_stream = atoi(v) != 0;
+  for (int l = 1; l < h->cfg.levels && e == hipSuccess; ++l) {
+    e = hipStreamCreateWithFlags(&h->side[l], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) return fail(h, MVAE_E_HIP, "bind: %s", hipGetErrorString(e));
   h->bound = true;
   return MVAE_OK;
@@ -587,62 +669,82 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
   const int B = io->batch, L = c.levels, C = c.input_c;
   if (B <= 0 || B > c.max_batch) return fail(h, MVAE_E_INVALID, "batch %d outside [1, %d]", B, c.max_batch);
   if (!io->x) return fail(h, MVAE_E_INVALID, "x is null");
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s0 = static_cast<hipStream_t>(stream);
   const bool training = io->training != 0;
   const float* P = h->dp;
   const int64_t hwC = (int64_t)c.input_h * c.input_w * C;
   float* metrics = h->dr + h->P + h->S;
-  (void)hipMemsetAsync(metrics, 0, sizeof(float) * h->MET, s);
+  const mvae_step_io io_c = *io;
+  // a replayable call: nothing injected, nothing copied out -> every pointer the kernels see is handle-owned
+  const bool replayable = !io->eps && !io->noise && !io->keep_mask && !io->recon && !io->mu && !io->log_var &&
+                          !io->z && !io->losses;
+  const float* xsrc = io->x;
+  if (replayable && h->use_graphs && !profiler().on && s0 != nullptr) {
+    (void)hipMemcpyAsync(h->xin, io->x, sizeof(float) * hwC * B, hipMemcpyDeviceToDevice, s0);
+    xsrc = h->xin;
+  }
+  launch_set_u64(h->d_seed, io->seed, s0);
+  const float* eps = io->eps ? io->eps : h->eps_buf;
 
-  // ---- randomness: injected (parity) or Philox on the device (timed runs)
-  const float* eps = io->eps;
-  if (!eps) { launch_rng_normal(h->eps_buf, (int64_t)B * h->Z, c.sample_std, io->seed, 1u, s); eps = h->eps_buf; }
-  const float *noise = nullptr, *keep = nullptr;
-  if (training) {
-    noise = io->noise; keep = io->keep_mask;
-    if (!noise) { launch_rng_normal(h->noise_buf, hwC * B, 1.0f, io->seed, 2u, s); noise = h->noise_buf; }
-    if (!keep) { launch_rng_keepmask(h->keep_buf, (int64_t)B * C, kDropout, io->seed, 3u, s); keep = h->keep_buf; }
-  }
-  // ---- input transform (multiscale_vae.py:129-160)
-  launch_prep(io->x, noise, keep, h->scales[0].pcur, B, c.input_h, c.input_w, C, c.min_value, c.max_value,
-              1.0f / (c.max_value - c.min_value), 1.0f / (1.0f - kDropout), s);
-  for (int l = 0; l + 1 < L; ++l) {
-    Scale& sc = h->scales[l];
-    launch_blur_split(sc.pcur, sc.band, h->scales[l + 1].pcur, B, sc.H, sc.W, C, s);
-  }
-  // ---- per-scale VAE
-  PreOp none{nullptr, nullptr, nullptr};
-  for (int si = 0; si < L; ++si) {
-    Scale& sc = h->scales[si];
-    ConvGeom g{};
-    g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
-    g.KH = g.KW = 3; g.SH = g.SW = 1; g.PT = g.PL = 1;
-    launch_conv_f(sc.band, P + sc.cb_w, P + sc.cb_b, nullptr, sc.e0, g, none, ACT_ELU, s);
-    const float* x = sc.e0;
-    for (Block& blk : sc.enc) {
-      if (blk.has_conv) {
-        ConvGeom cg = blk.cg; cg.B = B;
-        launch_conv_f(x, P + blk.cw, P + blk.cb, nullptr, blk.cout, cg, none, ACT_NONE, s);
-        x = blk.cout;
-      }
-      mn_forward(h, blk.mn, x, B, training, s);
-      x = blk.mn.out;
+  auto body = [=](hipStream_t s) {
+    const mvae_step_io* io = &io_c;
+    launch_zero(metrics, (int64_t)(h->MET), s);
+    // ---- randomness: injected (parity) or Philox on the device (timed runs)
+    if (!io->eps) launch_rng_normal(h->eps_buf, (int64_t)B * h->Z, c.sample_std, h->d_seed, 1u, s);
+    const float *noise = nullptr, *keep = nullptr;
+    if (training) {
+      noise = io->noise; keep = io->keep_mask;
+      if (!noise) { launch_rng_normal(h->noise_buf, hwC * B, 1.0f, h->d_seed, 2u, s); noise = h->noise_buf; }
+      if (!keep) { launch_rng_keepmask(h->keep_buf, (int64_t)B * C, kDropout, h->d_seed, 3u, s); keep = h->keep_buf; }
     }
-    launch_gemm_nn(x, P + sc.mu_w, P + sc.mu_b, sc.mu, nullptr, B, (int)sc.K, sc.z, ACT_NONE, s);
-    launch_gemm_nn(x, P + sc.lv_w, P + sc.lv_b, sc.lv, nullptr, B, (int)sc.K, sc.z, ACT_NONE, s);
-    launch_sample_kl(sc.mu, sc.lv, eps, (int)h->Z, sc.z_off, sc.zs, h->losses, 3 + L, 3 + si, B, sc.z, s);
-    if (io->mu) launch_copy_cols(sc.mu, sc.z, 0, io->mu, (int)h->Z, sc.z_off, B, sc.z, s);
-    if (io->log_var) launch_copy_cols(sc.lv, sc.z, 0, io->log_var, (int)h->Z, sc.z_off, B, sc.z, s);
-    if (io->z) launch_copy_cols(sc.zs, sc.z, 0, io->z, (int)h->Z, sc.z_off, B, sc.z, s);
-    decoder_forward(h, sc, B, training, s);
-  }
-  merge_forward(h, B, h->recon, s);
-  launch_loss_fwd(io->x, h->recon, h->losses, 3 + L, L, h->sgn, B, c.input_h, c.input_w, C, s);
-  launch_metrics(h->losses, 3 + L, B, metrics, s);
-  if (io->recon) (void)hipMemcpyAsync(io->recon, h->recon, sizeof(float) * hwC * B, hipMemcpyDeviceToDevice, s);
-  if (io->losses)
-    (void)hipMemcpyAsync(io->losses, h->losses, sizeof(float) * (3 + L) * B, hipMemcpyDeviceToDevice, s);
-  h->last_B = B; h->last_training = training; h->last_x = io->x; h->last_eps = eps;
+    // ---- input transform (multiscale_vae.py:129-160)
+    launch_prep(xsrc, noise, keep, h->scales[0].pcur, B, c.input_h, c.input_w, C, c.min_value, c.max_value,
+                1.0f / (c.max_value - c.min_value), 1.0f / (1.0f - kDropout), s);
+    for (int l = 0; l + 1 < L; ++l) {
+      Scale& sc = h->scales[l];
+      launch_blur_split(sc.pcur, sc.band, h->scales[l + 1].pcur, B, sc.H, sc.W, C, s);
+    }
+    // ---- per-scale VAE: the scales are independent until the merge -> one stream each
+    fork_scales(h, s);
+    PreOp none{nullptr, nullptr, nullptr};
+    for (int si = L - 1; si >= 0; --si) {
+      hipStream_t ss = scale_stream(h, si, s);
+      Scale& sc = h->scales[si];
+      ConvGeom g{};
+      g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
+      g.KH = g.KW = 3; g.SH = g.SW = 1; g.PT = g.PL = 1;
+      launch_conv_f(sc.band, P + sc.cb_w, P + sc.cb_b, nullptr, sc.e0, g, none, ACT_ELU, ss);
+      const float* x = sc.e0;
+      for (Block& blk : sc.enc) {
+        if (blk.has_conv) {
+          ConvGeom cg = blk.cg; cg.B = B;
+          launch_conv_f(x, P + blk.cw, P + blk.cb, nullptr, blk.cout, cg, none, ACT_NONE, ss);
+          x = blk.cout;
+        }
+        mn_forward(h, blk.mn, x, B, training, ss);
+        x = blk.mn.out;
+      }
+      launch_gemm_nn(x, P + sc.mu_w, P + sc.mu_b, sc.mu, nullptr, B, (int)sc.K, sc.z, ACT_NONE, ss);
+      launch_gemm_nn(x, P + sc.lv_w, P + sc.lv_b, sc.lv, nullptr, B, (int)sc.K, sc.z, ACT_NONE, ss);
+      launch_sample_kl(sc.mu, sc.lv, eps, (int)h->Z, sc.z_off, sc.zs, h->losses, 3 + L, 3 + si, B, sc.z, ss);
+      if (io->mu) launch_copy_cols(sc.mu, sc.z, 0, io->mu, (int)h->Z, sc.z_off, B, sc.z, ss);
+      if (io->log_var) launch_copy_cols(sc.lv, sc.z, 0, io->log_var, (int)h->Z, sc.z_off, B, sc.z, ss);
+      if (io->z) launch_copy_cols(sc.zs, sc.z, 0, io->z, (int)h->Z, sc.z_off, B, sc.z, ss);
+      decoder_forward(h, sc, B, training, ss);
+    }
+    join_scales(h, s);
+    merge_forward(h, B, h->recon, s);
+    launch_loss_fwd(xsrc, h->recon, h->losses, 3 + L, L, h->sgn, B, c.input_h, c.input_w, C, s);
+    launch_metrics(h->losses, 3 + L, B, metrics, s);
+    if (io->recon) (void)hipMemcpyAsync(io->recon, h->recon, sizeof(float) * hwC * B, hipMemcpyDeviceToDevice, s);
+    if (io->losses)
+      (void)hipMemcpyAsync(io->losses, h->losses, sizeof(float) * (3 + L) * B, hipMemcpyDeviceToDevice, s);
+  };
+  int rc = MVAE_OK;
+  if (replayable && xsrc == h->xin) rc = run_captured(h, fkey("F:%d:%d", B, training ? 1 : 0), s0, body);
+  else body(s0);
+  if (rc != MVAE_OK) return rc;
+  h->last_B = B; h->last_training = training; h->last_x = xsrc; h->last_eps = eps;
   if (training) h->last_train_B = B;
   return check_launch(h, "mvae_forward");
 }
@@ -653,17 +755,21 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     return fail(h, MVAE_E_STATE, "mvae_backward needs a preceding training-mode mvae_forward");
   const mvae_config& c = h->cfg;
   const int B = h->last_B, L = c.levels, C = c.input_c;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t s0 = static_cast<hipStream_t>(stream);
   const float* P = h->dp;
   float* G = h->dr;
+  auto body = [=](hipStream_t s) {
   PreOp none{nullptr, nullptr, nullptr};
-  (void)hipMemsetAsync(G, 0, sizeof(float) * h->P, s);
+  launch_zero(G, (int64_t)(h->P), s);
   // ---- loss -> clip/denormalise -> merge
   launch_loss_bwd(h->last_x, h->recon, h->scales[0].merged, h->sgn, h->scales[0].dy, B, c.input_h, c.input_w, C,
                   c.min_value, c.max_value, r_factor / (float)B, s);
   for (int i = 0; i + 1 < L; ++i)
     launch_upsample_bwd(h->scales[i].dy, h->scales[i + 1].dy, B, h->scales[i + 1].H, h->scales[i + 1].W, C, s);
-  for (int si = 0; si < L; ++si) {
+  fork_scales(h, s);
+  hipStream_t s_main = s;
+  for (int si = L - 1; si >= 0; --si) {
+    hipStream_t s = scale_stream(h, si, s_main);
     Scale& sc = h->scales[si];
     for (int k = 0; k < 4; ++k) sc.scratch_used[k] = false;
     const int64_t M = (int64_t)B * sc.H * sc.W;
@@ -674,8 +780,8 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     launch_conv_wgrad(xbn, sc.dy, G + sc.out_w, G + sc.out_b, go, bn, s);
     float* d = acquire(sc);
     launch_conv_t(sc.dy, P + sc.out_w, nullptr, nullptr, d, go, s);
-    (void)hipMemsetAsync(sc.bn_sum_d, 0, sizeof(float) * sc.dc, s);
-    (void)hipMemsetAsync(sc.bn_sum_dx, 0, sizeof(float) * sc.dc, s);
+    launch_zero(sc.bn_sum_d, (int64_t)(sc.dc), s);
+    launch_zero(sc.bn_sum_dx, (int64_t)(sc.dc), s);
     launch_bn_bwd_reduce(d, xbn, sc.bn_mean, sc.bn_invstd, sc.bn_sum_d, sc.bn_sum_dx, M, sc.dc, s);
     launch_bn2d_bwd_apply(d, xbn, sc.bn_mean, sc.bn_invstd, P + sc.bn_g, sc.bn_sum_d, sc.bn_sum_dx, G + sc.bn_g,
                           G + sc.bn_b, M, sc.dc, s);
@@ -728,18 +834,30 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     launch_conv_wgrad(sc.band, d, G + sc.cb_w, G + sc.cb_b, g, none, s);
     release(sc, d);
   }
+  join_scales(h, s_main);
+  };
+  int rc = MVAE_OK;
+  if (h->last_x == h->xin && h->last_eps == h->eps_buf)
+    rc = run_captured(h, fkey("B:%d:%a:%a", B, (double)r_factor, (double)kl_factor), s0, body);
+  else body(s0);
+  if (rc != MVAE_OK) return rc;
   return check_launch(h, "mvae_backward");
 }
 
 int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_scale, void* stream) {
   if (!h) return MVAE_E_INVALID;
   if (!h->bound) return fail(h, MVAE_E_STATE, "mvae_bind has not been called");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  (void)hipMemsetAsync(h->d_norms, 0, sizeof(float) * h->params.size(), s);
-  launch_opt_prepare(h->dp, h->dr, h->d_chunks, (int)h->chunks.size(), h->d_norms, grad_scale, s);
-  launch_opt_apply(h->dp, h->dr, h->da, h->d_chunks, (int)h->chunks.size(), h->d_norms, lr, clip_norm, s);
-  // BN moving statistics from the (all-reduced, hence grad_scale) batch statistics
-  launch_state_update(h->ds, h->dr + h->P, h->d_sdescs, (int)h->sdescs.size(), grad_scale, h->last_train_B, s);
+  hipStream_t s0 = static_cast<hipStream_t>(stream);
+  const int Bt = h->last_train_B;
+  auto body = [=](hipStream_t s) {
+    launch_zero(h->d_norms, (int64_t)(h->params.size()), s);
+    launch_opt_prepare(h->dp, h->dr, h->d_chunks, (int)h->chunks.size(), h->d_norms, grad_scale, s);
+    launch_opt_apply(h->dp, h->dr, h->da, h->d_chunks, (int)h->chunks.size(), h->d_norms, lr, clip_norm, s);
+    // BN moving statistics from the (all-reduced, hence grad_scale) batch statistics
+    launch_state_update(h->ds, h->dr + h->P, h->d_sdescs, (int)h->sdescs.size(), grad_scale, Bt, s);
+  };
+  int rc = run_captured(h, fkey("A:%d:%a:%a:%a", Bt, (double)lr, (double)clip_norm, (double)grad_scale), s0, body);
+  if (rc != MVAE_OK) return rc;
   return check_launch(h, "mvae_apply_adagrad");
 }
 
@@ -757,7 +875,7 @@ int mvae_reg_loss(mvae_handle* h, float* out_dev, void* stream) {
   if (!h || !out_dev) return MVAE_E_INVALID;
   if (!h->bound) return fail(h, MVAE_E_STATE, "mvae_bind has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  (void)hipMemsetAsync(out_dev, 0, sizeof(float), s);
+  launch_zero(out_dev, 1, s);
   launch_reg_loss(h->dp, h->d_chunks, (int)h->chunks.size(), out_dev, s);
   return check_launch(h, "mvae_reg_loss");
 }

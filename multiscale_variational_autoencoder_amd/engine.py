@@ -97,13 +97,24 @@ class Engine:
             if k.endswith(".var"):
                 st[v["offset"]:v["offset"] + v["shape"][0]] = 1.0
         self.state.copy_(torch.from_numpy(st))
+        torch.cuda.synchronize(self.device)
         self._check(self.lib.mvae_bind(self.h, device_index, _ptr(self.params), _ptr(self.reduce), _ptr(self.accum),
                                        _ptr(self.state), _ptr(self.workspace), self.workspace.numel() * 4))
+        # all kernels run on this stream: a real (non-default) HIP stream, so that the library can capture its
+        # launch sequences into hipGraphs; torch ops that touch our buffers are issued under it as well
+        self.stream = torch.cuda.Stream(self.device)
         self.bound = True
         return self
 
     def _stream(self):
-        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def _enter(self):
+        """Order our stream after whatever the caller enqueued on the current stream (input tensors)."""
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+
+    def sync(self):
+        self.stream.synchronize()
 
     def _pack(self, table, values, total):
         flat = np.zeros(total, np.float32)
@@ -121,26 +132,35 @@ class Engine:
             out[k] = flat[meta["offset"]:meta["offset"] + n].reshape(meta["shape"]).copy()
         return out
 
+    def _upload(self, dst, flat):
+        self.sync()
+        dst.copy_(self.torch.from_numpy(flat))
+        self.torch.cuda.synchronize(self.device)
+
+    def _download(self, src):
+        self.sync()
+        return src.cpu().numpy()
+
     def set_params(self, values):
-        self.params.copy_(self.torch.from_numpy(self._pack(self.param_table, values, self.P)))
+        self._upload(self.params, self._pack(self.param_table, values, self.P))
 
     def get_params(self):
-        return self._unpack(self.param_table, self.params.cpu().numpy())
+        return self._unpack(self.param_table, self._download(self.params))
 
     def set_accum(self, values):
-        self.accum.copy_(self.torch.from_numpy(self._pack(self.param_table, values, self.P)))
+        self._upload(self.accum, self._pack(self.param_table, values, self.P))
 
     def get_accum(self):
-        return self._unpack(self.param_table, self.accum.cpu().numpy())
+        return self._unpack(self.param_table, self._download(self.accum))
 
     def get_grads(self):
-        return self._unpack(self.param_table, self.reduce[:self.P].cpu().numpy())
+        return self._unpack(self.param_table, self._download(self.reduce[:self.P]))
 
     def set_state(self, values):
-        self.state.copy_(self.torch.from_numpy(self._pack(self.state_table, values, max(self.S, 1))))
+        self._upload(self.state, self._pack(self.state_table, values, max(self.S, 1)))
 
     def get_state(self):
-        return self._unpack(self.state_table, self.state.cpu().numpy())
+        return self._unpack(self.state_table, self._download(self.state))
 
     def to_device(self, a):
         t = self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
@@ -168,7 +188,10 @@ class Engine:
         if "losses" in outputs:
             out["losses"] = torch.empty((B, 3 + self.levels), **f32); io.losses = out["losses"].data_ptr()
         self._keep = (x, eps, noise, keep_mask)       # backward reads x / eps again
+        self._enter()
         self._check(self.lib.mvae_forward(self.h, C.byref(io), self._stream()))
+        if out:
+            self.sync()                               # the caller reads the outputs from another stream
         return out
 
     def backward(self, r_factor, kl_factor):
@@ -185,13 +208,14 @@ class Engine:
         scale = 1.0
         dist = self.torch.distributed
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.reduce)                  # grads | BN batch statistics | metrics, one message
+            with self.torch.cuda.stream(self.stream):
+                dist.all_reduce(self.reduce)              # grads | BN batch statistics | metrics, one message
             scale = 1.0 / dist.get_world_size()
         self.apply(lr, clip_norm, scale)
 
     def metrics(self):
         """{count, vae_r_loss, r_exp, vae_kl_loss, kl_scale_i} means of the last forward (synchronises)."""
-        m = self.reduce[self.metrics_off:self.metrics_off + 4 + self.levels].cpu().numpy().astype(np.float64)
+        m = self._download(self.reduce[self.metrics_off:self.metrics_off + 4 + self.levels]).astype(np.float64)
         n = max(m[0], 1.0)
         out = dict(count=m[0], vae_r_loss=m[1] / n, r_exp=m[2] / n, vae_kl_loss=m[3] / n)
         for s in range(self.levels):
@@ -200,7 +224,9 @@ class Engine:
 
     def reg_loss(self):
         t = self.torch.zeros(1, dtype=self.torch.float32, device=self.device)
+        self._enter()
         self._check(self.lib.mvae_reg_loss(self.h, _ptr(t), self._stream()))
+        self.sync()
         return float(t.item())
 
     def decode(self, z):
@@ -209,7 +235,9 @@ class Engine:
         if z.shape[1] != self.Z or z.dtype != torch.float32 or not z.is_contiguous():
             raise ValueError("z must be a contiguous float32 tensor [B,%d]" % self.Z)
         out = torch.empty((B,) + self.input_dims, dtype=torch.float32, device=self.device)
+        self._enter()
         self._check(self.lib.mvae_decode(self.h, _ptr(z), B, _ptr(out), self._stream()))
+        self.sync()
         return out
 
     def tensor(self, name, batch):
@@ -219,4 +247,5 @@ class Engine:
         if rc != _abi.MVAE_OK:
             raise KeyError(name)
         off = (p.value - self.workspace.data_ptr()) // 4
+        self.sync()
         return self.workspace[off:off + batch * n.value].view(batch, n.value)

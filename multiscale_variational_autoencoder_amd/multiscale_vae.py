@@ -274,14 +274,16 @@ class MultiscaleVAE:
                         continue
                     idx = idx[rank * per:(rank + 1) * per]
                 eng = self.train_on_batch(x[idx])
-                m = eng.reduce[eng.metrics_off:eng.metrics_off + 4 + self._levels]
-                acc = m.clone() if acc is None else acc + m    # stays on the device: no per-step sync
+                with torch.cuda.stream(eng.stream):            # stays on the device: no per-step sync
+                    m = eng.reduce[eng.metrics_off:eng.metrics_off + 4 + self._levels]
+                    acc = m.clone() if acc is None else acc + m
                 seen += 1
                 for cb in callbacks:
                     if hasattr(cb, "on_batch_end"):
                         cb.on_batch_end(bi, {})
             logs = {}
             if acc is not None:
+                eng.sync()
                 a = acc.cpu().numpy().astype(np.float64)
                 cnt = max(a[0], 1.0)
                 logs = {"vae_r_loss": a[1] / cnt, "vae_kl_loss": a[3] / cnt}
