@@ -148,4 +148,17 @@ void set_gauss_constants(const float* g9);
 void launch_bn2d_mean(const float* sum, const float* mov_mean, float* mean, int64_t M, int C, int training,
                       hipStream_t s);
 
+
+// ---- edge layers (kernels_edge.hip); return false when the shape is not covered ----
+bool launch_convbase_fwd(const float* in, const float* W, const float* bias, float* out, int B, int H, int Wd, int CI,
+                         int CO, hipStream_t s);
+bool launch_convbase_wgrad(const float* in, const float* dy, const float* y, float* dW, float* db, int B, int H, int Wd,
+                           int CI, int CO, hipStream_t s);
+bool launch_head_fwd(const float* x, const float* scale, const float* shift, const float* W, const float* bias,
+                     float* y, int64_t M, int dc, int C, hipStream_t s);
+bool launch_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, float* S1, float* S2, float* dW,
+                     float* db, float* dout, int64_t M, int dc, int C, hipStream_t s);
+void launch_add_vec2(float* o0, const float* a0, float* o1, const float* a1, int n, hipStream_t s);
+
 }  // namespace mvae

@@ -1,0 +1,309 @@
+// kernels_edge.hip -- the two "edge" layers of every per-scale VAE, whose channel counts (3 <-> 32) fit neither
+// the MFMA tiles nor the generic kernels well, fused so that each makes the minimum number of passes over its
+// [B*H*W, 32] tensor:
+//   * encoder conv_base: Conv2D(3x3, C->32, SAME) + ELU (multiscale_vae.py:333-341): forward, and a weight
+//     gradient that applies ELU' on the fly (its input is data: no backward-data);
+//   * decoder head: BatchNormalization(0.999, 1e-4) -> Conv2D(1x1, 32->C) (multiscale_vae.py:420-431): the
+//     forward folds BN into the conv read; the backward is ONE reduction pass (BN sums, dW, db) and ONE apply pass.
+#include "kernels.h"
+
+namespace mvae {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// -------------------------------------------------------------------------------------------------
+// conv_base forward: out[m, co] = elu(b[co] + sum_{tap,ci} in[gather(m,tap), ci] * W[tap][ci][co]),  CO = 32
+// block = 32 pixels x 8 lanes; a lane produces 4 output channels (one 16-byte store, 128 B per pixel)
+// -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_convbase_fwd(const float* __restrict__ in, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                      int H, int Wd, int CI) {
+  __shared__ __attribute__((aligned(16))) float sW[9 * 4 * 32];
+  for (int t = threadIdx.x; t < 9 * CI * 32; t += 256) sW[t] = W[t];
+  __syncthreads();
+  const int c4 = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const f32x4 b4 = reinterpret_cast<const f32x4*>(bias)[c4];
+  const int64_t M = (int64_t)B * H * Wd;
+  for (int64_t p = (int64_t)blockIdx.x * 32 + pl; p < M; p += (int64_t)gridDim.x * 32) {
+    const int x = (int)(p % Wd);
+    const int64_t q = p / Wd;
+    const int y = (int)(q % H);
+    const int64_t b = q / H;
+    f32x4 acc = b4;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int yy = y + a - 1;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int xx = x + e - 1;
+        if (xx < 0 || xx >= Wd) continue;
+        const float* ip = in + ((b * H + yy) * Wd + xx) * CI;
+        const float* wp = sW + (a * 3 + e) * CI * 32 + c4 * 4;
+        for (int ci = 0; ci < CI; ++ci) acc += ip[ci] * *reinterpret_cast<const f32x4*>(wp + ci * 32);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = acc[k] > 0.f ? acc[k] : expm1f(acc[k]);
+    reinterpret_cast<f32x4*>(out)[p * 8 + c4] = acc;
+  }
+}
+
+// conv_base weight gradient with ELU' fused: dpre = dy * (y > 0 ? 1 : y + 1);
+//   dW[tap][ci][co] += sum_m in[gather(m,tap), ci] * dpre[m, co] ;  db[co] += sum_m dpre[m, co]
+// block = 32 output channels x 8 pixel lanes; 9*CI + 1 accumulators per thread (CI <= 4)
+__global__ void __launch_bounds__(256) k_convbase_wgrad(const float* __restrict__ in, const float* __restrict__ dy,
+                                                        const float* __restrict__ y, float* __restrict__ dW,
+                                                        float* __restrict__ db, int B, int H, int Wd, int CI,
+                                                        int64_t ppb) {
+  __shared__ float red[37 * 256];
+  const int co = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  float acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.f;
+  float accb = 0.f;
+  const int64_t M = (int64_t)B * H * Wd;
+  const int64_t p0 = (int64_t)blockIdx.x * ppb;
+  int64_t p1 = p0 + ppb;
+  if (p1 > M) p1 = M;
+  for (int64_t p = p0 + pl; p < p1; p += 8) {
+    const float yv = y[p * 32 + co];
+    const float d = dy[p * 32 + co] * (yv > 0.f ? 1.0f : yv + 1.0f);
+    accb += d;
+    const int x = (int)(p % Wd);
+    const int64_t q = p / Wd;
+    const int yy0 = (int)(q % H);
+    const int64_t b = q / H;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int yy = yy0 + a - 1;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int xx = x + e - 1;
+        if (xx < 0 || xx >= Wd) continue;
+        const float* ip = in + ((b * H + yy) * Wd + xx) * CI;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+          if (ci < CI) acc[(a * 3 + e) * 4 + ci] += ip[ci] * d;
+      }
+    }
+  }
+  // reduce the 8 pixel lanes through LDS (static register indices only: no scratch)
+#pragma unroll
+  for (int k = 0; k < 36; ++k) red[k * 256 + threadIdx.x] = acc[k];
+  red[36 * 256 + threadIdx.x] = accb;
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int k = 0; k < 37; ++k) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += red[k * 256 + r * 32 + co];
+      if (k < 36) {
+        const int tap = k >> 2, ci = k & 3;
+        if (ci < CI) atomicAdd(&dW[(tap * CI + ci) * 32 + co], t);
+      } else {
+        atomicAdd(&db[co], t);
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// decoder head.  DC4 = dc/4 lanes per pixel (dc = BatchNorm channels, a power of two >= 4), C <= 8 outputs.
+// forward: y[m,o] = b[o] + sum_c (x[m,c] * scale[c] + shift[c]) * W[c][o]
+// -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_head_fwd(const f32x4* __restrict__ x, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, float* __restrict__ yout, int64_t M,
+                                                  int dc4, int C) {
+  const int c4 = threadIdx.x % dc4, pl = threadIdx.x / dc4, ppb = 256 / dc4;
+  const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4], sh = reinterpret_cast<const f32x4*>(shift)[c4];
+  float w[4][8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int o = 0; o < 8; ++o) w[e][o] = o < C ? W[(c4 * 4 + e) * C + o] : 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * ppb + pl; p < M; p += (int64_t)gridDim.x * ppb) {
+    const f32x4 v = x[p * dc4 + c4] * sc + sh;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = v[0] * w[0][o] + v[1] * w[1][o] + v[2] * w[2][o] + v[3] * w[3][o];
+    for (int off = 1; off < dc4; off <<= 1) {
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+        if (o < C) acc[o] += __shfl_xor(acc[o], off, 64);
+    }
+    if (c4 == 0) {
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+        if (o < C) yout[p * C + o] = acc[o] + bias[o];
+    }
+  }
+}
+
+// backward pass 1 (reduction): with dxbn[m,c] = sum_o dy[m,o] W[c][o], xhat = (x - mean) * invstd,
+//   S1[c] += dxbn ; S2[c] += dxbn * xhat ; dW[c][o] += (x*scale+shift) * dy[m,o] ; db[o] += dy[m,o]
+__global__ void __launch_bounds__(256) k_head_bwd_reduce(const f32x4* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ W, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, float* __restrict__ S1,
+                                                         float* __restrict__ S2, float* __restrict__ dW,
+                                                         float* __restrict__ db, int64_t M, int dc4, int C, int64_t ppb) {
+  __shared__ float red[48 * 256];
+  const int c4 = threadIdx.x % dc4, pl = threadIdx.x / dc4, npl = 256 / dc4;
+  const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4], sh = reinterpret_cast<const f32x4*>(shift)[c4];
+  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+  float w[4][8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int o = 0; o < 8; ++o) w[e][o] = o < C ? W[(c4 * 4 + e) * C + o] : 0.f;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, gw[4][8], gb[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    gb[o] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gw[e][o] = 0.f;
+  }
+  const int64_t p0 = (int64_t)blockIdx.x * ppb;
+  int64_t p1 = p0 + ppb;
+  if (p1 > M) p1 = M;
+  for (int64_t p = p0 + pl; p < p1; p += npl) {
+    const f32x4 xv = x[p * dc4 + c4];
+    float d[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) d[o] = o < C ? dy[p * C + o] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float dx = 0.f;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) dx += d[o] * w[e][o];
+      const float xh = (xv[e] - mu[e]) * is[e], xb = xv[e] * sc[e] + sh[e];
+      s1[e] += dx;
+      s2[e] += dx * xh;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) gw[e][o] += xb * d[o];
+    }
+    if (c4 == 0) {
+#pragma unroll
+      for (int o = 0; o < 8; ++o) gb[o] += d[o];
+    }
+  }
+  // block reduction over the pixel lanes through LDS; quantity q: s1 0..3, s2 4..7, gw 8 + 8e + o, gb 40 + o
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[e * 256 + threadIdx.x] = s1[e];
+    red[(4 + e) * 256 + threadIdx.x] = s2[e];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) red[(8 + e * 8 + o) * 256 + threadIdx.x] = gw[e][o];
+  }
+#pragma unroll
+  for (int o = 0; o < 8; ++o) red[(40 + o) * 256 + threadIdx.x] = gb[o];
+  __syncthreads();
+  if (pl == 0) {
+    auto total = [&](int q) {
+      float t = 0.f;
+      for (int r = 0; r < npl; ++r) t += red[q * 256 + r * dc4 + c4];
+      return t;
+    };
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(&S1[c4 * 4 + e], total(e));
+      atomicAdd(&S2[c4 * 4 + e], total(4 + e));
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+        if (o < C) atomicAdd(&dW[(c4 * 4 + e) * C + o], total(8 + e * 8 + o));
+    }
+    if (c4 == 0) {
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+        if (o < C) atomicAdd(&db[o], total(40 + o));
+    }
+  }
+}
+
+// backward pass 2 (apply): d[m,c] = gamma*invstd * (dxbn - S1/M - xhat * S2/M)
+__global__ void __launch_bounds__(256) k_head_bwd_apply(const f32x4* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ W, const float* __restrict__ gamma,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, const float* __restrict__ S1,
+                                                        const float* __restrict__ S2, f32x4* __restrict__ dout,
+                                                        int64_t M, int dc4, int C) {
+  const int c4 = threadIdx.x % dc4, pl = threadIdx.x / dc4, ppb = 256 / dc4;
+  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+  const f32x4 gm = reinterpret_cast<const f32x4*>(gamma)[c4];
+  const float inv_m = 1.0f / (float)M;
+  const f32x4 m1 = reinterpret_cast<const f32x4*>(S1)[c4] * inv_m, m2 = reinterpret_cast<const f32x4*>(S2)[c4] * inv_m;
+  float w[4][8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int o = 0; o < 8; ++o) w[e][o] = o < C ? W[(c4 * 4 + e) * C + o] : 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * ppb + pl; p < M; p += (int64_t)gridDim.x * ppb) {
+    const f32x4 xv = x[p * dc4 + c4];
+    float d[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) d[o] = o < C ? dy[p * C + o] : 0.f;
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float dx = 0.f;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) dx += d[o] * w[e][o];
+      const float xh = (xv[e] - mu[e]) * is[e];
+      r[e] = gm[e] * is[e] * (dx - m1[e] - xh * m2[e]);
+    }
+    dout[p * dc4 + c4] = r;
+  }
+}
+
+// ---- launchers (false = shape not covered, caller uses the generic kernels) -----------------------------------
+static inline int cap_grid(int64_t g) { return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g)); }
+
+bool launch_convbase_fwd(const float* in, const float* W, const float* bias, float* out, int B, int H, int Wd, int CI,
+                         int CO, hipStream_t s) {
+  if (CO != 32 || CI > 4) return false;
+  int64_t M = (int64_t)B * H * Wd;
+  hipLaunchKernelGGL(k_convbase_fwd, dim3(cap_grid((M + 31) / 32)), dim3(256), 0, s, in, W, bias, out, B, H, Wd, CI);
+  return true;
+}
+bool launch_convbase_wgrad(const float* in, const float* dy, const float* y, float* dW, float* db, int B, int H, int Wd,
+                           int CI, int CO, hipStream_t s) {
+  if (CO != 32 || CI > 4) return false;
+  int64_t M = (int64_t)B * H * Wd;
+  int64_t ppb = 512;
+  while ((M + ppb - 1) / ppb > 1024) ppb *= 2;
+  hipLaunchKernelGGL(k_convbase_wgrad, dim3((unsigned)((M + ppb - 1) / ppb)), dim3(256), 0, s, in, dy, y, dW, db, B, H,
+                     Wd, CI, ppb);
+  return true;
+}
+static bool head_ok(int dc, int C) {
+  if (C > 8 || dc < 4 || dc > 256 || (dc & (dc - 1))) return false;
+  return true;
+}
+bool launch_head_fwd(const float* x, const float* scale, const float* shift, const float* W, const float* bias,
+                     float* y, int64_t M, int dc, int C, hipStream_t s) {
+  if (!head_ok(dc, C)) return false;
+  const int dc4 = dc / 4, ppb = 256 / dc4;
+  hipLaunchKernelGGL(k_head_fwd, dim3(cap_grid((M + ppb - 1) / ppb)), dim3(256), 0, s, (const f32x4*)x, scale, shift, W,
+                     bias, y, M, dc4, C);
+  return true;
+}
+bool launch_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, float* S1, float* S2, float* dW,
+                     float* db, float* dout, int64_t M, int dc, int C, hipStream_t s) {
+  if (!head_ok(dc, C)) return false;
+  const int dc4 = dc / 4, npl = 256 / dc4;
+  int64_t ppb = 1024;
+  while ((M + ppb - 1) / ppb > 1024) ppb *= 2;
+  hipLaunchKernelGGL(k_head_bwd_reduce, dim3((unsigned)((M + ppb - 1) / ppb)), dim3(256), 0, s, (const f32x4*)x, dy, W,
+                     scale, shift, mean, invstd, S1, S2, dW, db, M, dc4, C, ppb);
+  hipLaunchKernelGGL(k_head_bwd_apply, dim3(cap_grid((M + npl - 1) / npl)), dim3(256), 0, s, (const f32x4*)x, dy, W,
+                     gamma, mean, invstd, S1, S2, (f32x4*)dout, M, dc4, C);
+  return true;
+}
+
+}  // namespace mvae

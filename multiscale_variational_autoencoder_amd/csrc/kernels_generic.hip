@@ -810,6 +810,9 @@ __global__ void k_add_vec2(float* o0, const float* a0, float* o1, const float* a
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { o0[i] += a0[i]; o1[i] += a1[i]; }
 }
+void launch_add_vec2(float* o0, const float* a0, float* o1, const float* a1, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_add_vec2, dim3((n + 63) / 64), dim3(64), 0, s, o0, a0, o1, a1, n);
+}
 void launch_bn2d_bwd_apply(float* d, const float* x, const float* mean, const float* invstd, const float* gamma,
                            const float* sum_d, const float* sum_dx, float* dgamma, float* dbeta, int64_t M, int C,
                            hipStream_t s) {

@@ -463,9 +463,12 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
   launch_bn2d_finalize(sc.bn_sum, sc.bn_sqdev, P + sc.bn_g, P + sc.bn_b, h->ds + sc.st_bn_mean, h->ds + sc.st_bn_var,
                        sc.bn_mean, sc.bn_invstd, sc.bn_scale, sc.bn_shift, stats + sc.st_bn_mean,
                        stats + sc.st_bn_var, M, sc.dc, kDecBnEps, training ? 1 : 0, s);
-  ConvGeom g = geom1x1(B, sc.H, sc.W, sc.dc, sc.C);
-  PreOp bn{nullptr, sc.bn_scale, sc.bn_shift};
-  launch_conv_f(x, P + sc.out_w, P + sc.out_b, nullptr, sc.y, g, bn, ACT_NONE, s);
+  ProfScope ps("head_fwd", 4.0 * M * (sc.dc + sc.C), 2.0 * M * sc.dc * sc.C, s);
+  if (!launch_head_fwd(x, sc.bn_scale, sc.bn_shift, P + sc.out_w, P + sc.out_b, sc.y, M, sc.dc, sc.C, s)) {
+    ConvGeom g = geom1x1(B, sc.H, sc.W, sc.dc, sc.C);
+    PreOp bn{nullptr, sc.bn_scale, sc.bn_shift};
+    launch_conv_f(x, P + sc.out_w, P + sc.out_b, nullptr, sc.y, g, bn, ACT_NONE, s);
+  }
 }
 
 void merge_forward(mvae_handle* h, int B, float* recon, hipStream_t s) {
@@ -713,7 +716,11 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
       ConvGeom g{};
       g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
       g.KH = g.KW = 3; g.SH = g.SW = 1; g.PT = g.PL = 1;
-      launch_conv_f(sc.band, P + sc.cb_w, P + sc.cb_b, nullptr, sc.e0, g, none, ACT_ELU, ss);
+      {
+        ProfScope ps("convbase_fwd", 4.0 * B * sc.H * sc.W * (C + kConvBaseFilters), 2.0 * B * sc.H * sc.W * 9 * C * kConvBaseFilters, ss);
+        if (!launch_convbase_fwd(sc.band, P + sc.cb_w, P + sc.cb_b, sc.e0, B, sc.H, sc.W, C, kConvBaseFilters, ss))
+          launch_conv_f(sc.band, P + sc.cb_w, P + sc.cb_b, nullptr, sc.e0, g, none, ACT_ELU, ss);
+      }
       const float* x = sc.e0;
       for (Block& blk : sc.enc) {
         if (blk.has_conv) {
@@ -777,14 +784,24 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     const float* xbn = sc.dec.back().mn.out;
     ConvGeom go = geom1x1(B, sc.H, sc.W, sc.dc, C);
     PreOp bn{nullptr, sc.bn_scale, sc.bn_shift};
-    launch_conv_wgrad(xbn, sc.dy, G + sc.out_w, G + sc.out_b, go, bn, s);
     float* d = acquire(sc);
-    launch_conv_t(sc.dy, P + sc.out_w, nullptr, nullptr, d, go, s);
     launch_zero(sc.bn_sum_d, (int64_t)(sc.dc), s);
     launch_zero(sc.bn_sum_dx, (int64_t)(sc.dc), s);
-    launch_bn_bwd_reduce(d, xbn, sc.bn_mean, sc.bn_invstd, sc.bn_sum_d, sc.bn_sum_dx, M, sc.dc, s);
-    launch_bn2d_bwd_apply(d, xbn, sc.bn_mean, sc.bn_invstd, P + sc.bn_g, sc.bn_sum_d, sc.bn_sum_dx, G + sc.bn_g,
-                          G + sc.bn_b, M, sc.dc, s);
+    bool fused_head;
+    {
+      ProfScope ps("head_bwd", 4.0 * M * (3.0 * sc.dc + 2.0 * C), 6.0 * M * sc.dc * C, s);
+      fused_head = launch_head_bwd(xbn, sc.dy, P + sc.out_w, P + sc.bn_g, sc.bn_scale, sc.bn_shift, sc.bn_mean,
+                                   sc.bn_invstd, sc.bn_sum_d, sc.bn_sum_dx, G + sc.out_w, G + sc.out_b, d, M, sc.dc, C, s);
+    }
+    if (fused_head) {
+      launch_add_vec2(G + sc.bn_g, sc.bn_sum_dx, G + sc.bn_b, sc.bn_sum_d, sc.dc, s);
+    } else {
+      launch_conv_wgrad(xbn, sc.dy, G + sc.out_w, G + sc.out_b, go, bn, s);
+      launch_conv_t(sc.dy, P + sc.out_w, nullptr, nullptr, d, go, s);
+      launch_bn_bwd_reduce(d, xbn, sc.bn_mean, sc.bn_invstd, sc.bn_sum_d, sc.bn_sum_dx, M, sc.dc, s);
+      launch_bn2d_bwd_apply(d, xbn, sc.bn_mean, sc.bn_invstd, P + sc.bn_g, sc.bn_sum_d, sc.bn_sum_dx, G + sc.bn_g,
+                            G + sc.bn_b, M, sc.dc, s);
+    }
     // ---- decoder blocks, last to first
     for (int i = (int)sc.dec.size() - 1; i >= 0; --i) {
       Block& blk = sc.dec[i];
@@ -827,11 +844,19 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       }
     }
     // ---- conv_base (ELU): weight gradients only, its input is data
-    launch_elu_bwd(d, sc.e0, M * kConvBaseFilters, s);
-    ConvGeom g{};
-    g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
-    g.KH = g.KW = 3; g.SH = g.SW = 1; g.PT = g.PL = 1;
-    launch_conv_wgrad(sc.band, d, G + sc.cb_w, G + sc.cb_b, g, none, s);
+    bool fused_base;
+    {
+      ProfScope ps("convbase_wgrad", 4.0 * M * (2.0 * kConvBaseFilters + C), 2.0 * M * 9 * C * kConvBaseFilters, s);
+      fused_base = launch_convbase_wgrad(sc.band, d, sc.e0, G + sc.cb_w, G + sc.cb_b, B, sc.H, sc.W, C,
+                                         kConvBaseFilters, s);
+    }
+    if (!fused_base) {
+      launch_elu_bwd(d, sc.e0, M * kConvBaseFilters, s);
+      ConvGeom g{};
+      g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
+      g.KH = g.KW = 3; g.SH = g.SW = 1; g.PT = g.PL = 1;
+      launch_conv_wgrad(sc.band, d, G + sc.cb_w, G + sc.cb_b, g, none, s);
+    }
     release(sc, d);
   }
   join_scales(h, s_main);
