@@ -159,6 +159,12 @@ bool launch_head_fwd(const float* x, const float* scale, const float* shift, con
 bool launch_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,
                      const float* shift, const float* mean, const float* invstd, float* S1, float* S2, float* dW,
                      float* db, float* dout, int64_t M, int dc, int C, hipStream_t s);
+// sliding-row depthwise kernels (kernels_dw.hip); false = shape not covered
+bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* out, float* gap, int B, int H, int W,
+                       int C, hipStream_t s);
+bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
+                         const float* dgap, float* dt0, float* dW, float* db, int B, int H, int W, int C,
+                         hipStream_t s);
 void launch_add_vec2(float* o0, const float* a0, float* o1, const float* a1, int n, hipStream_t s);
 
 }  // namespace mvae

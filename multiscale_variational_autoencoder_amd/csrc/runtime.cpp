@@ -395,8 +395,15 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
   ConvGeom g = geom1x1(B, m.H, m.W, c, c);
   PreOp none{nullptr, nullptr, nullptr};
   launch_conv_f(x, P + m.w0, P + m.b0, nullptr, m.t0, g, none, ACT_RELU, s);
-  launch_dw_fwd(m.t0, P + m.wd, P + m.bd, m.t1, B, m.H, m.W, c, s);
-  launch_spatial_sum(m.t1, m.gap, B, (int64_t)m.H * m.W, c, 1.0f / (float)(m.H * m.W), s);
+  bool fused_dw;
+  {
+    ProfScope ps("dw_fwd_gap", 8.0 * B * m.H * m.W * c, 20.0 * B * m.H * m.W * c, s);
+    fused_dw = launch_dw_fwd_gap(m.t0, P + m.wd, P + m.bd, m.t1, m.gap, B, m.H, m.W, c, s);
+  }
+  if (!fused_dw) {
+    launch_dw_fwd(m.t0, P + m.wd, P + m.bd, m.t1, B, m.H, m.W, c, s);
+    launch_spatial_sum(m.t1, m.gap, B, (int64_t)m.H * m.W, c, 1.0f / (float)(m.H * m.W), s);
+  }
   launch_gemm_nn(m.gap, P + m.sw0, P + m.sb0, m.s0, nullptr, B, c, c, ACT_RELU, s);
   launch_bn1d_fwd(m.s0, P + m.gam, P + m.bet, h->ds + m.st_mean, h->ds + m.st_var, m.xhat, m.invstd, m.s1,
                   stats + m.st_mean, stats + m.st_var, B, c, kSeBnEps, training ? 1 : 0, s);
@@ -425,10 +432,17 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   launch_gemm_tn(m.gap, sc.dv, G + m.sw0, G + m.sb0, B, c, c, nullptr, nullptr, nullptr, s);
   launch_gemm_nt(sc.dv, P + m.sw0, sc.dgap, B, c, c, nullptr, 0, s);
   // through the gate multiply, the global average pool and the depthwise ReLU
-  launch_mn_dt1pre(bufB, m.t1, m.g, sc.dgap, B, HW, c, 1.0f / (float)HW, s);
-  launch_dw_wgrad(m.t0, bufB, G + m.wd, G + m.bd, B, m.H, m.W, c, s);
   float* bufC = acquire(sc);
-  launch_dw_bwd_data(bufB, P + m.wd, m.t0, bufC, B, m.H, m.W, c, s);                   // dt0pre
+  bool fused_dw;
+  {
+    ProfScope ps("dw_bwd_fused", 16.0 * B * HW * c, 40.0 * B * HW * c, s);
+    fused_dw = launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC, G + m.wd, G + m.bd, B, m.H, m.W, c, s);
+  }
+  if (!fused_dw) {
+    launch_mn_dt1pre(bufB, m.t1, m.g, sc.dgap, B, HW, c, 1.0f / (float)HW, s);
+    launch_dw_wgrad(m.t0, bufB, G + m.wd, G + m.bd, B, m.H, m.W, c, s);
+    launch_dw_bwd_data(bufB, P + m.wd, m.t0, bufC, B, m.H, m.W, c, s);                 // dt0pre
+  }
   launch_conv_wgrad(x, bufC, G + m.w0, G + m.b0, g, none, s);
   launch_conv_t(bufC, P + m.w0, nullptr, dout, bufB, g, s);                            // da = dt0pre.W0^T + dout
   release(sc, bufC);
