@@ -162,9 +162,10 @@ bool launch_head_bwd(const float* x, const float* dy, const float* W, const floa
 // sliding-row depthwise kernels (kernels_dw.hip); false = shape not covered
 bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* out, float* gap, int B, int H, int W,
                        int C, hipStream_t s);
+constexpr int kDwMaxBlocks = 1024;     // partial-sum scratch: kDwMaxBlocks * 10 * C floats
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
-                         const float* dgap, float* dt0, float* dW, float* db, int B, int H, int W, int C,
-                         hipStream_t s);
+                         const float* dgap, float* dt0, float* dW, float* db, float* partial, int B, int H, int W,
+                         int C, hipStream_t s);
 void launch_add_vec2(float* o0, const float* a0, float* o1, const float* a1, int n, hipStream_t s);
 
 }  // namespace mvae

@@ -97,8 +97,8 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const f32x4* __restrict__ i
 __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ dt2, const f32x4* __restrict__ t1,
                                                      const f32x4* __restrict__ t0, const f32x4* __restrict__ w,
                                                      const f32x4* __restrict__ gate, const f32x4* __restrict__ dgap,
-                                                     f32x4* __restrict__ dt0, float* __restrict__ dW,
-                                                     float* __restrict__ db, DwGeom g, float inv_hw, int B) {
+                                                     f32x4* __restrict__ dt0, f32x4* __restrict__ partial, DwGeom g,
+                                                     float inv_hw, int B, int RS, int nseg) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   f32x4* ring = reinterpret_cast<f32x4*>(dyn_lds);
   const int XSP = g.XS + 2;
@@ -111,8 +111,13 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
 #pragma unroll
   for (int k = 0; k < 9; ++k) { wt[k] = w[k * g.C4 + c4]; aw[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   f32x4 ab = {0.f, 0.f, 0.f, 0.f};
+  const int xl0 = threadIdx.x / g.C4, xl1 = (threadIdx.x + 256) / g.C4;     // this thread's (at most) two columns
+  const bool has0 = threadIdx.x < items && xl0 < xs_n, has1 = threadIdx.x + 256 < items && xl1 < xs_n;
 
-  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+  // work item = (image b, row segment seg): rows [ya, yb) need d1 rows ya-1 .. yb
+  for (int item = blockIdx.y; item < B * nseg; item += gridDim.y) {
+    const int b = item / nseg, seg = item % nseg;
+    const int ya = seg * RS, yb = min(g.H, ya + RS);
     const int64_t ioff = (int64_t)b * g.H * g.W * g.C4;
     auto load_row = [&](int y) {                      // d1 row y (with column halo) -> ring slot y & 3
       for (int t = threadIdx.x; t < row_items; t += 256) {
@@ -129,44 +134,48 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
         RING(y & 3, xs, cc) = v;
       }
     };
-    __syncthreads();                                  // previous image's ring reads are done
-    load_row(0);
-    for (int y = 0; y < g.H; ++y) {
+    __syncthreads();                                  // previous item's ring reads are done
+    if (ya > 0) load_row(ya - 1);
+    load_row(ya);
+    for (int y = ya; y < yb; ++y) {
+      // t0 of this row is independent of the ring: issue it before the barrier so both latencies overlap
+      const int64_t o0 = ioff + ((int64_t)y * g.W + x0 + xl0) * g.C4 + c4;
+      const int64_t o1 = ioff + ((int64_t)y * g.W + x0 + xl1) * g.C4 + c4;
+      f32x4 tv[2];
+      tv[0] = has0 ? t0[o0] : f32x4{0.f, 0.f, 0.f, 0.f};
+      tv[1] = has1 ? t0[o1] : f32x4{0.f, 0.f, 0.f, 0.f};
       if (y + 1 < g.H) load_row(y + 1);
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int idx = threadIdx.x + 256 * k;
-        if (idx < items) {
-          const int xl = idx / g.C4;
-          if (xl < xs_n) {
-            const int64_t o = ioff + ((int64_t)y * g.W + x0 + xl) * g.C4 + c4;
-            const f32x4 tv = t0[o];
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            // position (y,x) was read by output pixel (y-a+1, x-e+1) through tap (a,e)
+        if (k == 0 ? has0 : has1) {
+          const int xl = k == 0 ? xl0 : xl1;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          // position (y,x) was read by output pixel (y-a+1, x-e+1) through tap (a,e)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-              const int yy = y - a + 1;
-              if (yy < 0 || yy >= g.H) continue;
+          for (int a = 0; a < 3; ++a) {
+            const int yy = y - a + 1;
+            if (yy < 0 || yy >= g.H) continue;
 #pragma unroll
-              for (int e = 0; e < 3; ++e) {
-                const f32x4 s = RING(yy & 3, xl + 2 - e, c4);      // column x - e + 1 -> ring column xl + 2 - e
-                acc += wt[a * 3 + e] * s;
-                aw[a * 3 + e] += tv * s;
-              }
+            for (int e = 0; e < 3; ++e) {
+              const f32x4 sv = RING(yy & 3, xl + 2 - e, c4);     // column x - e + 1 -> ring column xl + 2 - e
+              acc += wt[a * 3 + e] * sv;
+              aw[a * 3 + e] += tv[k] * sv;
             }
-            ab += RING(y & 3, xl + 1, c4);
-            f32x4 r;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = tv[q] > 0.f ? acc[q] : 0.f;
-            dt0[o] = r;
           }
+          ab += RING(y & 3, xl + 1, c4);
+          f32x4 r;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) r[q] = tv[k][q] > 0.f ? acc[q] : 0.f;
+          dt0[k == 0 ? o0 : o1] = r;
         }
       }
     }
   }
-  // ---- block reduction of the 10 float4 accumulators over the threads that share c4, then atomics
+  // ---- block reduction of the 10 float4 accumulators over the threads that share c4; the block's partial goes
+  //      out with plain stores (summed by k_dw_partials: deterministic, no contended float atomics)
   f32x4* red = ring;                                  // needs 256 float4 = 4 KB <= ring size (checked by launcher)
+  f32x4* pout = partial + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 10 * g.C4;
 #pragma unroll
   for (int k = 0; k < 10; ++k) {
     __syncthreads();
@@ -175,11 +184,30 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
     if (threadIdx.x < g.C4) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
       for (int r = threadIdx.x; r < 256; r += g.C4) t += red[r];
-      float* dst = k < 9 ? dW + ((int64_t)k * g.C4 + threadIdx.x) * 4 : db + threadIdx.x * 4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) atomicAdd(dst + q, t[q]);
+      pout[k * g.C4 + threadIdx.x] = t;
     }
   }
+}
+
+// dW[k][c] += sum_blocks partial[blk][k][c] (k < 9) ; db[c] += sum_blocks partial[blk][9][c]
+// blockIdx.y splits the block axis into 32 chunks (each thread sums <= nblk/32 partials, then one float atomic)
+__global__ void __launch_bounds__(256) k_dw_partials(const float* __restrict__ partial, int nblk, float* __restrict__ dW,
+                                                     float* __restrict__ db, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 10 * C) return;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  int bk = b0;
+  for (; bk + 3 < b1; bk += 4) {
+    t0 += partial[(int64_t)bk * 10 * C + i];
+    t1 += partial[(int64_t)(bk + 1) * 10 * C + i];
+    t2 += partial[(int64_t)(bk + 2) * 10 * C + i];
+    t3 += partial[(int64_t)(bk + 3) * 10 * C + i];
+  }
+  for (; bk < b1; ++bk) t0 += partial[(int64_t)bk * 10 * C + i];
+  const float t = (t0 + t1) + (t2 + t3);
+  if (b1 > b0) atomicAdd(i < 9 * C ? &dW[i] : &db[i - 9 * C], t);
 }
 #undef RING
 
@@ -208,17 +236,26 @@ bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* o
   return true;
 }
 
-// fused backward through Multiply/GAP/ReLU + depthwise backward-data + depthwise weight/bias gradients
+// fused backward through Multiply/GAP/ReLU + depthwise backward-data + depthwise weight/bias gradients.
+// `partial` is a scratch buffer of kDwMaxBlocks * 10 * C floats.
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
-                         const float* dgap, float* dt0, float* dW, float* db, int B, int H, int W, int C,
-                         hipStream_t s) {
+                         const float* dgap, float* dt0, float* dW, float* db, float* partial, int B, int H, int W,
+                         int C, hipStream_t s) {
   DwGeom g;
   size_t lds;
-  if (!dw_geom(H, W, C, &g, &lds)) return false;
-  int gy = B < 512 ? B : 512;                         // each block walks B/gy images: bounds the float atomics
+  if (!dw_geom(H, W, C, &g, &lds) || !partial) return false;
+  // split images into row segments until ~2048 work items exist (each costs two halo rows of re-reads)
+  int nseg = 1;
+  while ((int64_t)B * g.strips * nseg < 2048 && H / (nseg * 2) >= 2) nseg *= 2;
+  const int RS = (H + nseg - 1) / nseg;
+  nseg = (H + RS - 1) / RS;
+  int64_t work = (int64_t)B * nseg;
+  int gy = (int)(work < kDwMaxBlocks / g.strips ? work : kDwMaxBlocks / g.strips);
+  if (gy < 1) return false;
   hipLaunchKernelGGL(k_dw_bwd_ring, dim3(g.strips, gy), dim3(256), lds, s, (const f32x4*)dt2, (const f32x4*)t1,
-                     (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0, dW, db, g,
-                     1.0f / (float)(H * W), B);
+                     (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0,
+                     (f32x4*)partial, g, 1.0f / (float)(H * W), B, RS, nseg);
+  hipLaunchKernelGGL(k_dw_partials, dim3((10 * C + 255) / 256, 32), dim3(256), 0, s, partial, g.strips * gy, dW, db, C);
   return true;
 }
 

@@ -66,7 +66,7 @@ struct Scale {
   float* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   bool scratch_used[4] = {false, false, false, false};
   int cmax = 0;
-  float *dg, *dgap, *ds1, *dv, *dz, *dmu, *dlv;
+  float *dg, *dgap, *ds1, *dv, *dz, *dmu, *dlv, *dw_part;
 };
 
 }  // namespace
@@ -298,6 +298,7 @@ int build_plan(mvae_handle* h) {
     int64_t cm = sc.cmax;
     sc.dg = as_ptr(b.act("", cm)); sc.dgap = as_ptr(b.act("", cm));
     sc.ds1 = as_ptr(b.act("", cm)); sc.dv = as_ptr(b.act("", cm));
+    sc.dw_part = as_ptr(b.ws_alloc((int64_t)kDwMaxBlocks * 10 * cm));
     sc.dz = as_ptr(b.act("", sc.z)); sc.dmu = as_ptr(b.act("", sc.z)); sc.dlv = as_ptr(b.act("", sc.z));
     H /= 2; W /= 2;
   }
@@ -359,6 +360,7 @@ void rebase_all(mvae_handle* h) {
     if (alias_m) sc.merged = sc.y; else rb(sc.merged);
     rb(sc.dy);
     for (int k = 0; k < 4; ++k) rb(sc.scratch[k]);
+    rb(sc.dw_part);
     rb(sc.dg); rb(sc.dgap); rb(sc.ds1); rb(sc.dv); rb(sc.dz); rb(sc.dmu); rb(sc.dlv);
   }
   rb(h->xin);
@@ -436,7 +438,8 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   bool fused_dw;
   {
     ProfScope ps("dw_bwd_fused", 16.0 * B * HW * c, 40.0 * B * HW * c, s);
-    fused_dw = launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC, G + m.wd, G + m.bd, B, m.H, m.W, c, s);
+    fused_dw = launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC, G + m.wd, G + m.bd, sc.dw_part, B, m.H,
+                                   m.W, c, s);
   }
   if (!fused_dw) {
     launch_mn_dt1pre(bufB, m.t1, m.g, sc.dgap, B, HW, c, 1.0f / (float)HW, s);
