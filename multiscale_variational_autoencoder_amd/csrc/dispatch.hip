@@ -37,7 +37,8 @@ void launch_gemm_nt_generic(const float*, const float*, float*, int, int, int, c
 void launch_gemm_tn_generic(const float*, const float*, float*, float*, int, int, int, const float*, const float*,
                             const float*, hipStream_t);
 bool launch_conv1x1_mfma(bool transposed, const float* in, const float* w, const float* bias, const float* residual,
-                         float* out, const ConvGeom& g, PreOp pre, int act, hipStream_t s);
+                         float* out, const ConvGeom& g, PreOp pre, int act, const float* dot_src, float* dot_out,
+                         hipStream_t s);
 bool launch_gemm_tn_opt(const float*, const float*, float*, float*, int, int, int, const float*, const float*,
                         const float*, hipStream_t);
 bool launch_gemm_nn_opt(const float*, const float*, const float*, float*, float*, int, int, int, int, hipStream_t);
@@ -54,7 +55,7 @@ void launch_conv_f(const float* big, const float* w, const float* bias, const fl
                    ConvGeom g, PreOp pre, int act, hipStream_t s) {
   double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
   ProfScope ps(tagm(g.KH * g.KW == 1 ? "conv1x1_f" : "convkxk_f", (double)g.B * g.OH * g.OW), f4(nb + ns * (residual ? 2 : 1) + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
-  if (launch_conv1x1_mfma(false, big, w, bias, residual, small, g, pre, act, s)) return;
+  if (launch_conv1x1_mfma(false, big, w, bias, residual, small, g, pre, act, nullptr, nullptr, s)) return;
   if (g.KH * g.KW > 1 && !residual && !pre.gate && !pre.scale && act == ACT_NONE &&
       launch_conv_taps_mfma(false, big, w, bias, small, g, s)) return;
   launch_conv_f_generic(big, w, bias, residual, small, g, pre, act, s);
@@ -64,7 +65,7 @@ void launch_conv_t(const float* small, const float* w, const float* bias, const 
   double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
   ProfScope ps(tagm(g.KH * g.KW == 1 ? "conv1x1_t" : "convkxk_t", (double)g.B * g.IH * g.IW), f4(ns + nb * (residual ? 2 : 1) + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
   PreOp none{nullptr, nullptr, nullptr};
-  if (launch_conv1x1_mfma(true, small, w, bias, residual, big, g, none, ACT_NONE, s)) return;
+  if (launch_conv1x1_mfma(true, small, w, bias, residual, big, g, none, ACT_NONE, nullptr, nullptr, s)) return;
   if (g.KH * g.KW > 1 && !residual && launch_conv_taps_mfma(true, small, w, bias, big, g, s)) return;
   launch_conv_t_generic(small, w, bias, residual, big, g, s);
 }
@@ -120,6 +121,22 @@ void launch_gemm_tn(const float* a, const float* g, float* dW, float* db, int B,
   ProfScope ps(tagm("gemm_tn", (double)K * N), f4((double)B * K + (double)K * N + (double)B * N), 2.0 * B * K * N, s);
   if (launch_gemm_tn_opt(a, g, dW, db, B, K, N, a_scale, a_shift, hs_lin, s)) return;
   launch_gemm_tn_generic(a, g, dW, db, B, K, N, a_scale, a_shift, hs_lin, s);
+}
+
+// big = convT(small) for a 1x1 layer, and dot_out[b,c] = sum_hw big * dot_src in the same pass when the MFMA path
+// applies; otherwise the two separate launches.
+void launch_conv_t_dot(const float* small, const float* w, float* big, const float* dot_src, float* dot_out,
+                       ConvGeom g, hipStream_t s) {
+  const int64_t HW = (int64_t)g.IH * g.IW;
+  {
+    double nb = (double)g.B * HW * g.CI, ns = (double)g.B * HW * g.CO;
+    ProfScope ps(tagm("conv1x1_t_dot", (double)g.B * HW), f4(ns + 2 * nb), 2.0 * ns * g.CI, s);
+    PreOp none{nullptr, nullptr, nullptr};
+    launch_zero(dot_out, (int64_t)g.B * g.CI, s);
+    if (launch_conv1x1_mfma(true, small, w, nullptr, nullptr, big, g, none, ACT_NONE, dot_src, dot_out, s)) return;
+  }
+  launch_conv_t(small, w, nullptr, nullptr, big, g, s);
+  launch_spatial_dot(big, dot_src, dot_out, g.B, HW, g.CI, s);
 }
 
 }  // namespace mvae

@@ -44,6 +44,9 @@ void launch_conv_t(const float* small, const float* w, const float* bias, const 
 // dW[kh,kw,ci,co] += sum pre(big) * small ; db[co] += sum small (db nullable)   (both pre-zeroed by the caller)
 void launch_conv_wgrad(const float* big, const float* small, float* dW, float* db, ConvGeom g, PreOp pre,
                        hipStream_t s);
+// big = convT_1x1(small) and dot_out[b,c] = sum_hw big * dot_src, fused when the shape allows
+void launch_conv_t_dot(const float* small, const float* w, float* big, const float* dot_src, float* dot_out,
+                       ConvGeom g, hipStream_t s);
 // ELU backward in place: d *= (y > 0 ? 1 : y + 1)
 void launch_elu_bwd(float* d, const float* y, int64_t n, hipStream_t s);
 

@@ -44,7 +44,9 @@ template <int K, int N, bool WT>
 __global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, const float* __restrict__ W,
                                                    const float* __restrict__ bias, const float* __restrict__ residual,
                                                    float* __restrict__ Y, int64_t M, int64_t rows_per_image, PreOp pre,
-                                                   int act) {
+                                                   int act, const float* __restrict__ dot_src,
+                                                   float* __restrict__ dot_out) {
+  // optional fused reduction (squeeze-excite gate gradient): dot_out[b, n] += sum_{rows of image b} Y[m,n]*dot_src[m,n]
   constexpr int KH = K / 2;                    // k's per lane half
   constexpr int TS = (K > N ? K : N) + 4;      // padded LDS row stride (floats) of the A tile and of the C tile
   constexpr int NT = N / 32;
@@ -65,6 +67,7 @@ __global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, 
   const int64_t ntiles = (M + 127) / 128;
   const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
   const f32x4* R4 = reinterpret_cast<const f32x4*>(residual);
+  const f32x4* D4 = reinterpret_cast<const f32x4*>(dot_src);
   f32x4* Y4 = reinterpret_cast<f32x4*>(Y);
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (bias) bias4 = reinterpret_cast<const f32x4*>(bias)[sc4];
@@ -128,6 +131,7 @@ __global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + nt * 32 + i] = acc[nt][r];
     WAVE_LDS_SYNC();
+    f32x4 dsum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < ST; ++j) {
       const int r = j * RPS + sr;
@@ -138,30 +142,49 @@ __global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, 
         for (int e = 0; e < 4; ++e) v[e] = act_apply_m(v[e], act);
       }
       if (residual) v = v + res[j];
-      if (row < M) Y4[row * N4 + sc4] = v;
+      if (row < M) {
+        Y4[row * N4 + sc4] = v;
+        if (dot_src) dsum += v * D4[row * N4 + sc4];
+      }
+    }
+    if (dot_src) {
+      // lanes that share the channel chunk sc4 are N4 apart: fold them, then one atomic per channel per tile
+      // (the launcher guarantees rows_per_image % 32 == 0, so a 32-row tile never straddles two images)
+#pragma unroll
+      for (int off = N4; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dsum[e] += __shfl_xor(dsum[e], off, 64);
+      if (lane < N4 && row0 < M) {
+        float* dst = dot_out + (row0 / rows_per_image) * N + sc4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dst + e, dsum[e]);
+      }
     }
   }
 }
 
 template <int K, int N, bool WT>
 static void run_gemm_rows(const float* X, const float* W, const float* bias, const float* residual, float* Y,
-                          int64_t M, int64_t rows_per_image, PreOp pre, int act, hipStream_t s) {
+                          int64_t M, int64_t rows_per_image, PreOp pre, int act, const float* dot_src, float* dot_out,
+                          hipStream_t s) {
   int64_t ntiles = (M + 127) / 128;
   int grid = (int)(ntiles < 768 ? ntiles : 768);     // 256 CUs x 3 resident workgroups
   hipLaunchKernelGGL((k_gemm_rows<K, N, WT>), dim3(grid), dim3(256), 0, s, X, W, bias, residual, Y, M, rows_per_image,
-                     pre, act);
+                     pre, act, dot_src, dot_out);
 }
 
 // returns false when the shape is not covered (caller falls back to the generic kernel)
 bool launch_conv1x1_mfma(bool transposed, const float* in, const float* w, const float* bias, const float* residual,
-                         float* out, const ConvGeom& g, PreOp pre, int act, hipStream_t s) {
+                         float* out, const ConvGeom& g, PreOp pre, int act, const float* dot_src, float* dot_out,
+                         hipStream_t s) {
   if (g.KH != 1 || g.KW != 1 || g.SH != 1 || g.SW != 1) return false;
+  if (dot_src && (((int64_t)g.IH * g.IW) % 32) != 0) return false;
   const int K = transposed ? g.CO : g.CI, N = transposed ? g.CI : g.CO;
   const int64_t M = (int64_t)g.B * g.IH * g.IW, rpi = (int64_t)g.IH * g.IW;
 #define MVAE_GR(KK, NN)                                                                                   \
   if (K == KK && N == NN) {                                                                               \
-    if (transposed) run_gemm_rows<KK, NN, true>(in, w, bias, residual, out, M, rpi, pre, act, s);         \
-    else run_gemm_rows<KK, NN, false>(in, w, bias, residual, out, M, rpi, pre, act, s);                   \
+    if (transposed) run_gemm_rows<KK, NN, true>(in, w, bias, residual, out, M, rpi, pre, act, dot_src, dot_out, s);         \
+    else run_gemm_rows<KK, NN, false>(in, w, bias, residual, out, M, rpi, pre, act, dot_src, dot_out, s);                   \
     return true;                                                                                          \
   }
   MVAE_GR(64, 64) MVAE_GR(32, 32) MVAE_GR(64, 32) MVAE_GR(32, 64)

@@ -423,8 +423,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   ConvGeom g = geom1x1(B, m.H, m.W, c, c);
   PreOp none{nullptr, nullptr, nullptr};
   float* bufB = acquire(sc);
-  launch_conv_t(dout, P + m.w2, nullptr, nullptr, bufB, g, s);                        // dt2 = dout . W2^T
-  launch_spatial_dot(bufB, m.t1, sc.dg, B, HW, c, s);                                  // dg = sum_hw dt2 * t1
+  launch_conv_t_dot(dout, P + m.w2, bufB, m.t1, sc.dg, g, s);          // dt2 = dout . W2^T ; dg = sum_hw dt2 * t1
   PreOp gate{m.g, nullptr, nullptr};
   launch_conv_wgrad(m.t1, dout, G + m.w2, G + m.b2, g, gate, s);                       // dW2 = (t1*g)^T dout, db2
   // squeeze-excite backward
