@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Per-queue busy/gap analysis of one train step from a rocprofv3 --kernel-trace CSV."""
+import csv, glob, collections, sys
+f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
+rows = [r for r in csv.DictReader(open(f)) if 'mvae' in r['Kernel_Name']]
+for r in rows:
+    r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
+rows.sort(key=lambda r: r['s'])
+starts = [r['s'] for r in rows if 'k_set_u64' in r['Kernel_Name']]
+a, b = starts[-2], starts[-1]
+step = [r for r in rows if a <= r['s'] < b]
+print("step span ms %.3f kernels %d" % ((b - a) / 1e6, len(step)))
+byq = collections.defaultdict(list)
+for r in step:
+    byq[r['Queue_Id']].append(r)
+for q, rs in byq.items():
+    rs.sort(key=lambda r: r['s'])
+    busy = sum(r['e'] - r['s'] for r in rs)
+    gaps = [rs[i + 1]['s'] - rs[i]['e'] for i in range(len(rs) - 1)]
+    pos = [g for g in gaps if g > 0]
+    print("queue %s n %d busy %.3f ms span %.3f ms gaps %.3f ms (median gap %.1f us)" % (
+        q, len(rs), busy / 1e6, (rs[-1]['e'] - rs[0]['s']) / 1e6, sum(pos) / 1e6,
+        sorted(pos)[len(pos) // 2] / 1e3 if pos else 0))
+# union busy time over all queues (GPU doing anything)
+ev = sorted([(r['s'], 1) for r in step] + [(r['e'], -1) for r in step])
+busy, depth, last = 0, 0, None
+for t, d in ev:
+    if depth > 0: busy += t - last
+    depth += d; last = t
+print("any-queue busy %.3f ms" % (busy / 1e6))
