@@ -169,6 +169,16 @@ constexpr int kDwMaxBlocks = 1024;     // partial-sum scratch: kDwMaxBlocks * 10
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
                          const float* dgap, float* dt0, float* dW, float* db, float* partial, int B, int H, int W,
                          int C, hipStream_t s);
+// Dense layers around the latent (kernels_dense.hip); false = shape not covered
+bool launch_dense_mu_lv(const float* x, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
+                        float* mu, float* lv, int B, int K, int Z, hipStream_t s);
+bool launch_dense_dz(const float* dy, const float* W, float* dz, int B, int Z, int N, hipStream_t s);
+bool launch_dense_dflat(const float* dmu, const float* dlv, const float* Wmu, const float* Wlv, float* out, int B, int K,
+                        int Z, hipStream_t s);
+bool launch_dense_expand(const float* z, const float* W, const float* bias, float* out, int B, int Z, int N,
+                         hipStream_t s);
+bool launch_dense_wgrad_mu_lv(const float* flat, const float* dmu, const float* dlv, float* dWmu, float* dWlv,
+                              float* dbmu, float* dblv, int B, int K, int Z, hipStream_t s);
 void launch_add_vec2(float* o0, const float* a0, float* o1, const float* a1, int n, hipStream_t s);
 
 }  // namespace mvae

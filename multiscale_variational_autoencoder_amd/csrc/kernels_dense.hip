@@ -1,0 +1,203 @@
+// kernels_dense.hip -- the Dense layers around the latent (multiscale_vae.py:358-370 Flatten -> Dense mu / log_var,
+// :402-406 decoder Dense): skinny products, K or N = z <= 32 against 512 .. 524288.
+//   k_skinny_mfma   out[b, j] += sum_k A[b,k] * Wcol_j[k]     split-K over waves on v_mfma_f32_32x32x2_f32;
+//                   mu and log_var are produced by ONE launch (their weights are two column blocks of the B operand)
+//   k_dense_bwd2    dflat[b,k] = sum_j dmu[b,j] Wmu[k,j] + dlv[b,j] Wlv[k,j]   (one pass, 4 batch rows per block)
+//   k_dense_expand  out[b,n]   = bias[n] + sum_k z[b,k] W[k,n]                  (16-byte stores, 4 batch rows per block)
+//   k_outer_wide2   dWmu[k,j], dWlv[k,j] += sum_b flat[b,k] * {dmu,dlv}[b,j]    (flat is read once for both)
+#include "kernels.h"
+
+namespace mvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one wave = 32 batch rows x (up to) 32 output columns x KC reduction indices; lane half h owns [h*KC/2, (h+1)*KC/2).
+// NT = false: Wx stored [K][Nx] (Dense kernel as in Keras);  NT = true: Wx stored [Nx][K] (its transpose use).
+template <bool NT>
+__global__ void __launch_bounds__(256) k_skinny_mfma(const float* __restrict__ A, const float* __restrict__ W1,
+                                                     const float* __restrict__ W2, const float* __restrict__ bias1,
+                                                     const float* __restrict__ bias2, float* __restrict__ out1,
+                                                     float* __restrict__ out2, int B, int K, int N1, int N2, int KC,
+                                                     int nchunks) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int rt = (int)(gw / nchunks), kc = (int)(gw % nchunks);
+  if (rt * 32 >= B) return;
+  const int i = lane & 31, h = lane >> 5;
+  const int row = rt * 32 + i;
+  const bool rv = row < B;
+  const int half = KC / 2;
+  const int kbeg = kc * KC + h * half;
+  // this lane's B-operand column
+  const float* Wc = nullptr;
+  int jx = 0, Nx = 0;
+  if (i < N1) { Wc = W1; jx = i; Nx = N1; }
+  else if (i < N1 + N2) { Wc = W2; jx = i - N1; Nx = N2; }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* arow = A + (int64_t)row * K;
+  for (int q = 0; q < half; q += 4) {
+    const int k = kbeg + q;
+    f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+    if (k < K) {                                           // K % 4 == 0: a float4 is inside or outside as a whole
+      if (rv) a4 = *reinterpret_cast<const f32x4*>(arow + k);
+      if (Wc) {
+        if (NT) b4 = *reinterpret_cast<const f32x4*>(Wc + (int64_t)jx * K + k);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b4[e] = Wc[(int64_t)(k + e) * Nx + jx];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
+  }
+  if (!Wc) return;
+  float* out = (i < N1) ? out1 : out2;
+  const float bv = (kc == 0) ? ((i < N1) ? (bias1 ? bias1[jx] : 0.f) : (bias2 ? bias2[jx] : 0.f)) : 0.f;
+  // every output element lives in exactly one (lane, register): the k = 0 chunk adds the bias
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int orow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (orow < B) atomicAdd(&out[(int64_t)orow * Nx + jx], acc[r] + bv);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_dense_bwd2(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                    const float* __restrict__ W1, const float* __restrict__ W2,
+                                                    float* __restrict__ out, int B, int K, int Z) {
+  __shared__ float sg[4][64];
+  const int b0 = blockIdx.y * 4;
+  for (int t = threadIdx.x; t < 4 * 2 * Z; t += 256) {
+    const int r = t / (2 * Z), j = t % (2 * Z);
+    const int b = b0 + r;
+    sg[r][j] = b < B ? (j < Z ? g1[(int64_t)b * Z + j] : g2[(int64_t)b * Z + j - Z]) : 0.f;
+  }
+  __syncthreads();
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* w1 = W1 + (int64_t)k * Z;
+  const float* w2 = W2 + (int64_t)k * Z;
+  for (int j = 0; j < Z; ++j) {
+    const float a = w1[j], c = w2[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += sg[r][j] * a + sg[r][Z + j] * c;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (b0 + r < B) out[(int64_t)(b0 + r) * K + k] = acc[r];
+}
+
+__global__ void __launch_bounds__(256) k_dense_expand(const float* __restrict__ z, const f32x4* __restrict__ W,
+                                                      const f32x4* __restrict__ bias, f32x4* __restrict__ out, int B,
+                                                      int Z, int N4) {
+  __shared__ float sz[4][32];
+  const int b0 = blockIdx.y * 4;
+  for (int t = threadIdx.x; t < 4 * Z; t += 256) {
+    const int r = t / Z, j = t % Z;
+    sz[r][j] = (b0 + r < B) ? z[(int64_t)(b0 + r) * Z + j] : 0.f;
+  }
+  __syncthreads();
+  const int n4 = blockIdx.x * 256 + threadIdx.x;
+  if (n4 >= N4) return;
+  const f32x4 bv = bias[n4];
+  f32x4 acc[4] = {bv, bv, bv, bv};
+  for (int k = 0; k < Z; ++k) {
+    const f32x4 w = W[(int64_t)k * N4 + n4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += w * sz[r][k];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (b0 + r < B) out[(int64_t)(b0 + r) * N4 + n4] = acc[r];
+}
+
+// dW1[w][j] += sum_b wide[b,w] s1[b,j] ; dW2[w][j] += sum_b wide[b,w] s2[b,j] ; db1[j] += sum_b s1 ; db2 likewise
+__global__ void __launch_bounds__(256) k_outer_wide2(const float* __restrict__ wide, const float* __restrict__ s1,
+                                                     const float* __restrict__ s2, float* __restrict__ dW1,
+                                                     float* __restrict__ dW2, float* __restrict__ db1,
+                                                     float* __restrict__ db2, int B, int Wd, int Z, int bpc) {
+  __shared__ float ssm[64 * 32];
+  const int b0 = blockIdx.y * bpc, b1 = min(B, b0 + bpc);
+  for (int t = threadIdx.x; t < (b1 - b0) * 2 * Z; t += 256) {
+    const int r = t / (2 * Z), j = t % (2 * Z);
+    ssm[t] = j < Z ? s1[(int64_t)(b0 + r) * Z + j] : s2[(int64_t)(b0 + r) * Z + j - Z];
+  }
+  __syncthreads();
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  float acc[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+  if (w < Wd) {
+    for (int b = b0; b < b1; ++b) {
+      const float v = wide[(int64_t)b * Wd + w];
+      const float* sp = ssm + (b - b0) * 2 * Z;
+#pragma unroll
+      for (int j = 0; j < 32; ++j)
+        if (j < 2 * Z) acc[j] += v * sp[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j < 2 * Z) atomicAdd(j < Z ? &dW1[(int64_t)w * Z + j] : &dW2[(int64_t)w * Z + j - Z], acc[j]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 2 * Z) {
+    float t = 0.f;
+    for (int b = 0; b < b1 - b0; ++b) t += ssm[b * 2 * Z + threadIdx.x];
+    atomicAdd(threadIdx.x < Z ? &db1[threadIdx.x] : &db2[threadIdx.x - Z], t);
+  }
+}
+
+// ---- launchers; false = shape not covered ---------------------------------------------------------------------
+static void run_skinny(bool nt, const float* A, const float* W1, const float* W2, const float* b1, const float* b2,
+                       float* o1, float* o2, int B, int K, int N1, int N2, hipStream_t s) {
+  launch_zero(o1, (int64_t)B * N1, s);
+  if (N2) launch_zero(o2, (int64_t)B * N2, s);
+  int KC = 256;
+  while (KC > 8 && (int64_t)((B + 31) / 32) * ((K + KC - 1) / KC) < 512 && KC > 32) KC /= 2;   // >= ~512 waves
+  const int nchunks = (K + KC - 1) / KC;
+  const int64_t waves = (int64_t)((B + 31) / 32) * nchunks;
+  dim3 grid((unsigned)((waves + 3) / 4));
+  if (nt) hipLaunchKernelGGL(k_skinny_mfma<true>, grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, KC, nchunks);
+  else hipLaunchKernelGGL(k_skinny_mfma<false>, grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, KC, nchunks);
+}
+
+// mu = x Wmu + bmu ; lv = x Wlv + blv   (x [B,K], W [K,Z])
+bool launch_dense_mu_lv(const float* x, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
+                        float* mu, float* lv, int B, int K, int Z, hipStream_t s) {
+  if (2 * Z > 32 || K < 256 || (K % 4)) return false;
+  run_skinny(false, x, Wmu, Wlv, bmu, blv, mu, lv, B, K, Z, Z, s);
+  return true;
+}
+// dz[b,k] = sum_n dy[b,n] W[k,n]   (W [Z,N])
+bool launch_dense_dz(const float* dy, const float* W, float* dz, int B, int Z, int N, hipStream_t s) {
+  if (Z > 32 || N < 256 || (N % 4)) return false;
+  run_skinny(true, dy, W, nullptr, nullptr, nullptr, dz, nullptr, B, N, Z, 0, s);
+  return true;
+}
+bool launch_dense_dflat(const float* dmu, const float* dlv, const float* Wmu, const float* Wlv, float* out, int B, int K,
+                        int Z, hipStream_t s) {
+  if (2 * Z > 64) return false;
+  hipLaunchKernelGGL(k_dense_bwd2, dim3((K + 255) / 256, (B + 3) / 4), dim3(256), 0, s, dmu, dlv, Wmu, Wlv, out, B, K, Z);
+  return true;
+}
+bool launch_dense_expand(const float* z, const float* W, const float* bias, float* out, int B, int Z, int N,
+                         hipStream_t s) {
+  if (Z > 32 || (N % 4)) return false;
+  hipLaunchKernelGGL(k_dense_expand, dim3((N / 4 + 255) / 256, (B + 3) / 4), dim3(256), 0, s, z, (const f32x4*)W,
+                     (const f32x4*)bias, (f32x4*)out, B, Z, N / 4);
+  return true;
+}
+bool launch_dense_wgrad_mu_lv(const float* flat, const float* dmu, const float* dlv, float* dWmu, float* dWlv,
+                              float* dbmu, float* dblv, int B, int K, int Z, hipStream_t s) {
+  if (2 * Z > 32) return false;
+  int bpc = B >= 512 ? 64 : (B >= 64 ? 32 : B);
+  if (bpc < 1) bpc = 1;
+  hipLaunchKernelGGL(k_outer_wide2, dim3((K + 255) / 256, (B + bpc - 1) / bpc), dim3(256), 0, s, flat, dmu, dlv, dWmu,
+                     dWlv, dbmu, dblv, B, K, Z, bpc);
+  return true;
+}
+
+}  // namespace mvae

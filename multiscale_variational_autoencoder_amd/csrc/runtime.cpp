@@ -65,6 +65,12 @@ struct Scale {
   int64_t scratch_elems = 0;
   float* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   bool scratch_used[4] = {false, false, false, false};
+  // weight-gradient side stream of this scale: wgrad kernels are off the backward dependency chain, they run
+  // concurrently with it; a scratch buffer they still read is guarded by ev_buf until it is recycled
+  hipStream_t wstream = nullptr;
+  hipEvent_t ev_prod = nullptr, ev_wjoin = nullptr, ev_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool buf_pending[4] = {false, false, false, false};
+  int lru[4] = {0, 0, 0, 0}, tick = 0;
   int cmax = 0;
   float *dg, *dgap, *ds1, *dv, *dz, *dmu, *dlv, *dw_part;
 };
@@ -97,10 +103,14 @@ struct mvae_handle {
   int64_t off_seed = 0;
   // concurrency: scale 0 runs on the caller's stream, every other scale on its own side stream (fork/join with
   // events); each ABI call is captured into a hipGraph per argument signature and replayed.
-  bool multi_stream = true, use_graphs = true;
+  // wgrad_streams: opt-in (MVAE_WGRAD_STREAMS=1).  Correct in eager mode, but the ~450 extra event calls per step
+  // make the host the bottleneck there, and capturing that many cross-stream edges crashes hipGraph (ROCm 7.2).
+  bool multi_stream = true, use_graphs = true, wgrad_streams = false;
   hipStream_t side[MVAE_MAX_LEVELS] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MVAE_MAX_LEVELS] = {};
   std::map<std::string, hipGraphExec_t> graphs;
+  std::vector<hipEvent_t> ev_pool;      // one fresh event per cross-stream edge of a backward pass
+  size_t ev_next = 0;
   // last forward
   int last_B = 0, last_train_B = 0;
   bool last_training = false;
@@ -372,14 +382,57 @@ void rebase_all(mvae_handle* h) {
 }
 
 // ---- scratch pool (per scale, static order => stable pointers under graph capture) ----------
-float* acquire(Scale& sc) {
+bool wgrad_async(mvae_handle* h) { return h->multi_stream && h->wgrad_streams && !profiler().on; }
+
+// least-recently-released free buffer; if a weight-gradient kernel may still be reading it, the chain waits for it
+float* acquire(mvae_handle* h, Scale& sc, hipStream_t chain) {
+  int best = -1;
   for (int k = 0; k < 4; ++k)
-    if (!sc.scratch_used[k]) { sc.scratch_used[k] = true; return sc.scratch[k]; }
-  return nullptr;
+    if (!sc.scratch_used[k] && (best < 0 || sc.lru[k] < sc.lru[best])) best = k;
+  if (best < 0) return nullptr;
+  sc.scratch_used[best] = true;
+  if (sc.buf_pending[best]) {
+    (void)hipStreamWaitEvent(chain, sc.ev_buf[best], 0);
+    sc.buf_pending[best] = false;
+  }
+  return sc.scratch[best];
 }
 void release(Scale& sc, float* p) {
   for (int k = 0; k < 4; ++k)
-    if (sc.scratch[k] == p) sc.scratch_used[k] = false;
+    if (sc.scratch[k] == p) { sc.scratch_used[k] = false; sc.lru[k] = ++sc.tick; }
+}
+hipEvent_t fresh_event(mvae_handle* h) {
+  if (h->ev_next == h->ev_pool.size()) {
+    hipEvent_t e = nullptr;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    h->ev_pool.push_back(e);
+  }
+  return h->ev_pool[h->ev_next++];
+}
+// stream for a weight-gradient launch whose inputs the chain has just produced (edge chain -> wstream)
+hipStream_t wgrad_begin(mvae_handle* h, Scale& sc, hipStream_t chain) {
+  if (!wgrad_async(h)) return chain;
+  hipEvent_t e = fresh_event(h);
+  (void)hipEventRecord(e, chain);
+  (void)hipStreamWaitEvent(sc.wstream, e, 0);
+  return sc.wstream;
+}
+// the launches just issued on `w` read pool buffer `p`: it must not be recycled before they finish
+void wgrad_reads(mvae_handle* h, Scale& sc, const float* p, hipStream_t w) {
+  if (!wgrad_async(h)) return;
+  for (int k = 0; k < 4; ++k)
+    if (sc.scratch[k] == p) {
+      sc.ev_buf[k] = fresh_event(h);
+      (void)hipEventRecord(sc.ev_buf[k], w);
+      sc.buf_pending[k] = true;
+    }
+}
+void wgrad_join(mvae_handle* h, Scale& sc, hipStream_t chain) {
+  if (!wgrad_async(h)) return;
+  hipEvent_t e = fresh_event(h);
+  (void)hipEventRecord(e, sc.wstream);
+  (void)hipStreamWaitEvent(chain, e, 0);
+  for (int k = 0; k < 4; ++k) sc.buf_pending[k] = false;
 }
 
 ConvGeom geom1x1(int B, int H, int W, int ci, int co) {
@@ -422,10 +475,14 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   const int64_t HW = (int64_t)m.H * m.W;
   ConvGeom g = geom1x1(B, m.H, m.W, c, c);
   PreOp none{nullptr, nullptr, nullptr};
-  float* bufB = acquire(sc);
+  float* bufB = acquire(h, sc, s);
+  {
+    hipStream_t w = wgrad_begin(h, sc, s);                                             // dout is ready on the chain
+    PreOp gate{m.g, nullptr, nullptr};
+    launch_conv_wgrad(m.t1, dout, G + m.w2, G + m.b2, g, gate, w);                     // dW2 = (t1*g)^T dout, db2
+    wgrad_reads(h, sc, dout, w);
+  }
   launch_conv_t_dot(dout, P + m.w2, bufB, m.t1, sc.dg, g, s);          // dt2 = dout . W2^T ; dg = sum_hw dt2 * t1
-  PreOp gate{m.g, nullptr, nullptr};
-  launch_conv_wgrad(m.t1, dout, G + m.w2, G + m.b2, g, gate, s);                       // dW2 = (t1*g)^T dout, db2
   // squeeze-excite backward
   launch_gemm_tn(m.xhat, sc.dg, G + m.sw1, G + m.sb1, B, c, c, P + m.gam, P + m.bet, m.ulin, s);
   launch_gemm_nt(sc.dg, P + m.sw1, sc.ds1, B, c, c, m.ulin, 0, s);
@@ -433,7 +490,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   launch_gemm_tn(m.gap, sc.dv, G + m.sw0, G + m.sb0, B, c, c, nullptr, nullptr, nullptr, s);
   launch_gemm_nt(sc.dv, P + m.sw0, sc.dgap, B, c, c, nullptr, 0, s);
   // through the gate multiply, the global average pool and the depthwise ReLU
-  float* bufC = acquire(sc);
+  float* bufC = acquire(h, sc, s);
   bool fused_dw;
   {
     ProfScope ps("dw_bwd_fused", 16.0 * B * HW * c, 40.0 * B * HW * c, s);
@@ -445,7 +502,11 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
     launch_dw_wgrad(m.t0, bufB, G + m.wd, G + m.bd, B, m.H, m.W, c, s);
     launch_dw_bwd_data(bufB, P + m.wd, m.t0, bufC, B, m.H, m.W, c, s);                 // dt0pre
   }
-  launch_conv_wgrad(x, bufC, G + m.w0, G + m.b0, g, none, s);
+  {
+    hipStream_t w = wgrad_begin(h, sc, s);                                             // dt0pre is ready on the chain
+    launch_conv_wgrad(x, bufC, G + m.w0, G + m.b0, g, none, w);
+    wgrad_reads(h, sc, bufC, w);
+  }
   launch_conv_t(bufC, P + m.w0, nullptr, dout, bufB, g, s);                            // da = dt0pre.W0^T + dout
   release(sc, bufC);
   release(sc, dout);
@@ -455,7 +516,12 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
 void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_t s) {
   const float* P = h->dp;
   float* stats = h->dr + h->P;
-  launch_gemm_nn(sc.zs, P + sc.dd_w, P + sc.dd_b, sc.d0, nullptr, B, sc.z, (int)sc.K, ACT_NONE, s);
+  bool fused_dd;
+  {
+    ProfScope ps("dense_expand", 4.0 * (B * (double)sc.K + sc.K * sc.z), 2.0 * B * sc.K * sc.z, s);
+    fused_dd = launch_dense_expand(sc.zs, P + sc.dd_w, P + sc.dd_b, sc.d0, B, sc.z, (int)sc.K, s);
+  }
+  if (!fused_dd) launch_gemm_nn(sc.zs, P + sc.dd_w, P + sc.dd_b, sc.d0, nullptr, B, sc.z, (int)sc.K, ACT_NONE, s);
   const float* x = sc.d0;
   for (Block& blk : sc.dec) {
     if (blk.has_conv) {
@@ -608,6 +674,10 @@ void mvae_destroy(mvae_handle* h) {
       if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (Scale& sc : h->scales) {
+      if (sc.wstream) (void)hipStreamDestroy(sc.wstream);
+    }
+    for (hipEvent_t ev : h->ev_pool) (void)hipEventDestroy(ev);
   }
   delete h;
 }
@@ -670,9 +740,21 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   set_gauss_constants(gf);
   if (const char* v = getenv("MVAE_GRAPHS")) h->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("MVAE_STREAMS")) h->multi_stream = atoi(v) != 0;
+  if (const char* v = getenv("MVAE_WGRAD_STREAMS")) h->wgrad_streams = atoi(v) != 0;
+  if (h->wgrad_streams) h->use_graphs = false;
   for (int l = 1; l < h->cfg.levels && e == hipSuccess; ++l) {
     e = hipStreamCreateWithFlags(&h->side[l], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming);
+  }
+  for (Scale& sc : h->scales) {
+    if (e != hipSuccess) break;
+    e = hipStreamCreateWithFlags(&sc.wstream, hipStreamNonBlocking);
+  }
+  // cross-stream edges of one backward pass: pre-created, so that no event is created while a capture is open
+  for (int k = 0; h->wgrad_streams && k < 2048 && e == hipSuccess; ++k) {
+    hipEvent_t ev = nullptr;
+    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) h->ev_pool.push_back(ev);
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -747,8 +829,16 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
         mn_forward(h, blk.mn, x, B, training, ss);
         x = blk.mn.out;
       }
-      launch_gemm_nn(x, P + sc.mu_w, P + sc.mu_b, sc.mu, nullptr, B, (int)sc.K, sc.z, ACT_NONE, ss);
-      launch_gemm_nn(x, P + sc.lv_w, P + sc.lv_b, sc.lv, nullptr, B, (int)sc.K, sc.z, ACT_NONE, ss);
+      bool fused_heads;
+      {
+        ProfScope ps("dense_mu_lv", 4.0 * (B * (double)sc.K + 2.0 * sc.K * sc.z), 4.0 * B * sc.K * sc.z, ss);
+        fused_heads = launch_dense_mu_lv(x, P + sc.mu_w, P + sc.mu_b, P + sc.lv_w, P + sc.lv_b, sc.mu, sc.lv, B,
+                                         (int)sc.K, sc.z, ss);
+      }
+      if (!fused_heads) {
+        launch_gemm_nn(x, P + sc.mu_w, P + sc.mu_b, sc.mu, nullptr, B, (int)sc.K, sc.z, ACT_NONE, ss);
+        launch_gemm_nn(x, P + sc.lv_w, P + sc.lv_b, sc.lv, nullptr, B, (int)sc.K, sc.z, ACT_NONE, ss);
+      }
       launch_sample_kl(sc.mu, sc.lv, eps, (int)h->Z, sc.z_off, sc.zs, h->losses, 3 + L, 3 + si, B, sc.z, ss);
       if (io->mu) launch_copy_cols(sc.mu, sc.z, 0, io->mu, (int)h->Z, sc.z_off, B, sc.z, ss);
       if (io->log_var) launch_copy_cols(sc.lv, sc.z, 0, io->log_var, (int)h->Z, sc.z_off, B, sc.z, ss);
@@ -783,6 +873,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
   float* G = h->dr;
   auto body = [=](hipStream_t s) {
   PreOp none{nullptr, nullptr, nullptr};
+  h->ev_next = 0;
   launch_zero(G, (int64_t)(h->P), s);
   // ---- loss -> clip/denormalise -> merge
   launch_loss_bwd(h->last_x, h->recon, h->scales[0].merged, h->sgn, h->scales[0].dy, B, c.input_h, c.input_w, C,
@@ -794,13 +885,13 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
   for (int si = L - 1; si >= 0; --si) {
     hipStream_t s = scale_stream(h, si, s_main);
     Scale& sc = h->scales[si];
-    for (int k = 0; k < 4; ++k) sc.scratch_used[k] = false;
+    for (int k = 0; k < 4; ++k) { sc.scratch_used[k] = false; sc.buf_pending[k] = false; }
     const int64_t M = (int64_t)B * sc.H * sc.W;
     // ---- output conv + decoder BatchNorm
     const float* xbn = sc.dec.back().mn.out;
     ConvGeom go = geom1x1(B, sc.H, sc.W, sc.dc, C);
     PreOp bn{nullptr, sc.bn_scale, sc.bn_shift};
-    float* d = acquire(sc);
+    float* d = acquire(h, sc, s);
     launch_zero(sc.bn_sum_d, (int64_t)(sc.dc), s);
     launch_zero(sc.bn_sum_dx, (int64_t)(sc.dc), s);
     bool fused_head;
@@ -826,24 +917,57 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       d = mn_backward(h, sc, blk.mn, xin, d, B, s);
       if (blk.has_conv) {     // Conv2DTranspose: big = its output (d), small = its input (prev)
         ConvGeom g = blk.cg; g.B = B;
-        launch_conv_wgrad(d, prev, G + blk.cw, nullptr, g, none, s);
-        launch_colsum(d, G + blk.cb, (int64_t)B * g.IH * g.IW, g.CI, s);
-        float* n = acquire(sc);
+        {
+          hipStream_t w = wgrad_begin(h, sc, s);
+          launch_conv_wgrad(d, prev, G + blk.cw, nullptr, g, none, w);
+          launch_colsum(d, G + blk.cb, (int64_t)B * g.IH * g.IW, g.CI, w);
+          wgrad_reads(h, sc, d, w);
+        }
+        float* n = acquire(h, sc, s);
         launch_conv_f(d, P + blk.cw, nullptr, nullptr, n, g, none, ACT_NONE, s);
         release(sc, d);
         d = n;
       }
     }
     // ---- decoder Dense, sampling + KL, encoder Dense heads
-    launch_gemm_tn(sc.zs, d, G + sc.dd_w, G + sc.dd_b, B, sc.z, (int)sc.K, nullptr, nullptr, nullptr, s);
-    launch_gemm_nt(d, P + sc.dd_w, sc.dz, B, sc.z, (int)sc.K, nullptr, 0, s);
+    {
+      hipStream_t w = wgrad_begin(h, sc, s);
+      launch_gemm_tn(sc.zs, d, G + sc.dd_w, G + sc.dd_b, B, sc.z, (int)sc.K, nullptr, nullptr, nullptr, w);
+      wgrad_reads(h, sc, d, w);
+    }
+    bool fused_dz;
+    {
+      ProfScope ps("dense_dz", 4.0 * (B * (double)sc.K + sc.K * sc.z), 2.0 * B * sc.K * sc.z, s);
+      fused_dz = launch_dense_dz(d, P + sc.dd_w, sc.dz, B, sc.z, (int)sc.K, s);
+    }
+    if (!fused_dz) launch_gemm_nt(d, P + sc.dd_w, sc.dz, B, sc.z, (int)sc.K, nullptr, 0, s);
     launch_sample_kl_bwd(sc.dz, sc.mu, sc.lv, h->last_eps, (int)h->Z, sc.z_off, sc.dmu, sc.dlv,
                          kl_factor / (float)B, B, sc.z, s);
     const float* flat = sc.enc.back().mn.out;
-    launch_gemm_tn(flat, sc.dmu, G + sc.mu_w, G + sc.mu_b, B, (int)sc.K, sc.z, nullptr, nullptr, nullptr, s);
-    launch_gemm_tn(flat, sc.dlv, G + sc.lv_w, G + sc.lv_b, B, (int)sc.K, sc.z, nullptr, nullptr, nullptr, s);
-    launch_gemm_nt(sc.dmu, P + sc.mu_w, d, B, (int)sc.K, sc.z, nullptr, 0, s);
-    launch_gemm_nt(sc.dlv, P + sc.lv_w, d, B, (int)sc.K, sc.z, nullptr, 1, s);
+    {   // dmu / dlv are per-scale buffers written once per backward: safe to read from the side stream
+      hipStream_t w = wgrad_begin(h, sc, s);
+      bool fused_w;
+      {
+        ProfScope ps("dense_wgrad", 4.0 * (B * (double)sc.K + 2.0 * sc.K * sc.z), 4.0 * B * sc.K * sc.z, w);
+        fused_w = launch_dense_wgrad_mu_lv(flat, sc.dmu, sc.dlv, G + sc.mu_w, G + sc.lv_w, G + sc.mu_b, G + sc.lv_b, B,
+                                           (int)sc.K, sc.z, w);
+      }
+      if (!fused_w) {
+        launch_gemm_tn(flat, sc.dmu, G + sc.mu_w, G + sc.mu_b, B, (int)sc.K, sc.z, nullptr, nullptr, nullptr, w);
+        launch_gemm_tn(flat, sc.dlv, G + sc.lv_w, G + sc.lv_b, B, (int)sc.K, sc.z, nullptr, nullptr, nullptr, w);
+      }
+    }
+    release(sc, d);                              // the side stream may still read it: take another buffer
+    d = acquire(h, sc, s);
+    bool fused_df;
+    {
+      ProfScope ps("dense_dflat", 4.0 * (B * (double)sc.K + 2.0 * sc.K * sc.z), 4.0 * B * sc.K * sc.z, s);
+      fused_df = launch_dense_dflat(sc.dmu, sc.dlv, P + sc.mu_w, P + sc.lv_w, d, B, (int)sc.K, sc.z, s);
+    }
+    if (!fused_df) {
+      launch_gemm_nt(sc.dmu, P + sc.mu_w, d, B, (int)sc.K, sc.z, nullptr, 0, s);
+      launch_gemm_nt(sc.dlv, P + sc.lv_w, d, B, (int)sc.K, sc.z, nullptr, 1, s);
+    }
     // ---- encoder blocks, last to first
     for (int i = (int)sc.enc.size() - 1; i >= 0; --i) {
       Block& blk = sc.enc[i];
@@ -852,8 +976,12 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       d = mn_backward(h, sc, blk.mn, xin, d, B, s);
       if (blk.has_conv) {     // Conv2D: big = its input (prev), small = its output (d)
         ConvGeom g = blk.cg; g.B = B;
-        launch_conv_wgrad(prev, d, G + blk.cw, G + blk.cb, g, none, s);
-        float* n = acquire(sc);
+        {
+          hipStream_t w = wgrad_begin(h, sc, s);
+          launch_conv_wgrad(prev, d, G + blk.cw, G + blk.cb, g, none, w);
+          wgrad_reads(h, sc, d, w);
+        }
+        float* n = acquire(h, sc, s);
         launch_conv_t(d, P + blk.cw, nullptr, nullptr, n, g, s);
         release(sc, d);
         d = n;
@@ -866,6 +994,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       fused_base = launch_convbase_wgrad(sc.band, d, sc.e0, G + sc.cb_w, G + sc.cb_b, B, sc.H, sc.W, C,
                                          kConvBaseFilters, s);
     }
+    wgrad_join(h, sc, s);                       // every side-stream weight gradient of this scale is done
     if (!fused_base) {
       launch_elu_bwd(d, sc.e0, M * kConvBaseFilters, s);
       ConvGeom g{};
