@@ -116,37 +116,99 @@ __global__ void __launch_bounds__(256) k_dense_expand(const float* __restrict__ 
 }
 
 // dW1[w][j] += sum_b wide[b,w] s1[b,j] ; dW2[w][j] += sum_b wide[b,w] s2[b,j] ; db1[j] += sum_b s1 ; db2 likewise
+// one thread per wide column; the batch range of the block is walked in LDS-staged chunks of 64 rows.  With
+// gridDim.y == 1 a thread owns its outputs: plain stores into the zeroed arena, no atomics (deterministic).
 __global__ void __launch_bounds__(256) k_outer_wide2(const float* __restrict__ wide, const float* __restrict__ s1,
                                                      const float* __restrict__ s2, float* __restrict__ dW1,
                                                      float* __restrict__ dW2, float* __restrict__ db1,
                                                      float* __restrict__ db2, int B, int Wd, int Z, int bpc) {
   __shared__ float ssm[64 * 32];
   const int b0 = blockIdx.y * bpc, b1 = min(B, b0 + bpc);
-  for (int t = threadIdx.x; t < (b1 - b0) * 2 * Z; t += 256) {
-    const int r = t / (2 * Z), j = t % (2 * Z);
-    ssm[t] = j < Z ? s1[(int64_t)(b0 + r) * Z + j] : s2[(int64_t)(b0 + r) * Z + j - Z];
-  }
-  __syncthreads();
   const int w = blockIdx.x * 256 + threadIdx.x;
   float acc[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) acc[j] = 0.f;
-  if (w < Wd) {
-    for (int b = b0; b < b1; ++b) {
-      const float v = wide[(int64_t)b * Wd + w];
-      const float* sp = ssm + (b - b0) * 2 * Z;
-#pragma unroll
-      for (int j = 0; j < 32; ++j)
-        if (j < 2 * Z) acc[j] += v * sp[j];
+  float bsum = 0.f;
+  for (int c0 = b0; c0 < b1; c0 += 64) {
+    const int c1 = min(b1, c0 + 64);
+    __syncthreads();
+    for (int t = threadIdx.x; t < (c1 - c0) * 2 * Z; t += 256) {
+      const int r = t / (2 * Z), j = t % (2 * Z);
+      ssm[t] = j < Z ? s1[(int64_t)(c0 + r) * Z + j] : s2[(int64_t)(c0 + r) * Z + j - Z];
     }
+    __syncthreads();
+    if (w < Wd) {
+      for (int b = c0; b < c1; ++b) {
+        const float v = wide[(int64_t)b * Wd + w];
+        const float* sp = ssm + (b - c0) * 2 * Z;
 #pragma unroll
-    for (int j = 0; j < 32; ++j)
-      if (j < 2 * Z) atomicAdd(j < Z ? &dW1[(int64_t)w * Z + j] : &dW2[(int64_t)w * Z + j - Z], acc[j]);
+        for (int j = 0; j < 32; ++j)
+          if (j < 2 * Z) acc[j] += v * sp[j];
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * Z)
+      for (int b = 0; b < c1 - c0; ++b) bsum += ssm[b * 2 * Z + threadIdx.x];
   }
-  if (blockIdx.x == 0 && threadIdx.x < 2 * Z) {
-    float t = 0.f;
-    for (int b = 0; b < b1 - b0; ++b) t += ssm[b * 2 * Z + threadIdx.x];
-    atomicAdd(threadIdx.x < Z ? &db1[threadIdx.x] : &db2[threadIdx.x - Z], t);
+  if (w < Wd) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if (j < 2 * Z) {
+        float* dst = j < Z ? &dW1[(int64_t)w * Z + j] : &dW2[(int64_t)w * Z + j - Z];
+        if (gridDim.y == 1) *dst += acc[j];
+        else atomicAdd(dst, acc[j]);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 2 * Z)
+    atomicAdd(threadIdx.x < Z ? &db1[threadIdx.x] : &db2[threadIdx.x - Z], bsum);
+}
+
+// MFMA form of the same gradient: a wave owns K-slice [k0, k0+32) and all 2Z <= 32 columns; D[i = k][j] accumulates
+// over the batch two rows per instruction (lane half h takes row b + h).  Operands are channel-on-lane, so the
+// loads are 128-byte row segments; the wave owns its outputs: plain stores, deterministic.
+__global__ void __launch_bounds__(256) k_dense_wgrad_mfma(const float* __restrict__ flat, const float* __restrict__ g1,
+                                                          const float* __restrict__ g2, float* __restrict__ dW1,
+                                                          float* __restrict__ dW2, float* __restrict__ db1,
+                                                          float* __restrict__ db2, int B, int K, int Z) {
+  // block = one K-slice of 32; its 4 waves split the batch, partial tiles are summed through LDS
+  __shared__ float red[4][16][64];
+  __shared__ float redb[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = blockIdx.x * 32;
+  const int i = lane & 31, h = lane >> 5;
+  const bool kv = k0 + i < K;
+  const float* gsrc = i < Z ? g1 : g2;
+  const int jx = i < Z ? i : i - Z;
+  const bool jv = i < 2 * Z;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  const int per = ((B + 7) / 8) * 2;                 // rows per wave, even
+  const int bb = wave * per, be = min(B, bb + per);
+#pragma unroll 8
+  for (int b = bb; b < be; b += 2) {
+    const int row = b + h;
+    const bool rv = row < be;
+    const float a = (rv && kv) ? flat[(int64_t)row * K + k0 + i] : 0.f;
+    const float g = (rv && jv) ? gsrc[(int64_t)row * Z + jx] : 0.f;
+    bsum += g;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, g, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (h == 0) redb[wave][i] = bsum;
+  __syncthreads();
+  if (wave == 0 && jv) {
+    float* dW = i < Z ? dW1 : dW2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float t = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+      if (k < K) dW[(int64_t)k * Z + jx] += t;
+    }
+    if (blockIdx.x == 0 && h == 0) (i < Z ? db1 : db2)[jx] += redb[0][i] + redb[1][i] + redb[2][i] + redb[3][i];
   }
 }
 
@@ -193,6 +255,11 @@ bool launch_dense_expand(const float* z, const float* W, const float* bias, floa
 bool launch_dense_wgrad_mu_lv(const float* flat, const float* dmu, const float* dlv, float* dWmu, float* dWlv,
                               float* dbmu, float* dblv, int B, int K, int Z, hipStream_t s) {
   if (2 * Z > 32) return false;
+  if (K >= 1024) {
+    hipLaunchKernelGGL(k_dense_wgrad_mfma, dim3((K + 31) / 32), dim3(256), 0, s, flat, dmu, dlv, dWmu, dWlv, dbmu,
+                       dblv, B, K, Z);
+    return true;
+  }
   int bpc = B >= 512 ? 64 : (B >= 64 ? 32 : B);
   if (bpc < 1) bpc = 1;
   hipLaunchKernelGGL(k_outer_wide2, dim3((K + 255) / 256, (B + bpc - 1) / bpc), dim3(256), 0, s, flat, dmu, dlv, dWmu,
