@@ -110,6 +110,65 @@ __global__ void __launch_bounds__(256) k_convbase_wgrad(const float* __restrict_
   }
 }
 
+// MFMA form of the conv_base weight gradient for 9*CI <= 32 (C <= 3): the [27 x 32] gradient is ONE 32x32 tile,
+// D[i = patch element k][j = co] += patch[m][k] * dpre[m][co], two pixels m per v_mfma_f32_32x32x2_f32.
+// A wave walks whole image rows; lane i decodes its patch element (a, e, ci) once.  4 waves reduce through LDS.
+typedef float f32x16e __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) k_convbase_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ dy,
+                                                             const float* __restrict__ y, float* __restrict__ dW,
+                                                             float* __restrict__ db, int B, int H, int Wd, int CI,
+                                                             int rows_per_wave) {
+  __shared__ float red[4][16][64];
+  __shared__ float redb[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int KP = 9 * CI;
+  const bool kv = i < KP;
+  const int tap = kv ? i / CI : 0, ci = kv ? i % CI : 0, a = tap / 3, e = tap % 3;
+  f32x16e acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  const int64_t nrows = (int64_t)B * H;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
+  for (int64_t rr = r0; rr < r0 + rows_per_wave && rr < nrows; ++rr) {
+    const int yy0 = (int)(rr % H);
+    const int64_t b = rr / H;
+    const int yy = yy0 + a - 1;
+    const bool yok = kv && yy >= 0 && yy < H;
+    const float* irow = in + ((b * H + (yok ? yy : 0)) * Wd) * CI + ci;
+    const float* drow = dy + rr * Wd * 32 + i;
+    const float* yrow = y + rr * Wd * 32 + i;
+#pragma unroll 4
+    for (int x = 0; x < Wd; x += 2) {
+      const int xm = x + h;                       // this lane half's pixel
+      const bool mv = xm < Wd;
+      const int xx = xm + e - 1;
+      const float av = (mv && yok && xx >= 0 && xx < Wd) ? irow[xx * CI] : 0.f;
+      float d = 0.f;
+      if (mv) {
+        const float yv = yrow[xm * 32];
+        d = drow[xm * 32] * (yv > 0.f ? 1.0f : yv + 1.0f);
+      }
+      bsum += d;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, d, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (h == 0) redb[wave][i] = bsum;
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = (r & 3) + 8 * (r >> 2) + 4 * h;          // patch element (row of D), column = co = i
+      if (k < KP) atomicAdd(&dW[k * 32 + i], red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane]);
+    }
+    if (h == 0) atomicAdd(&db[i], redb[0][i] + redb[1][i] + redb[2][i] + redb[3][i]);
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // decoder head.  DC4 = dc/4 lanes per pixel (dc = BatchNorm channels, a power of two >= 4), C <= 8 outputs.
 // forward: y[m,o] = b[o] + sum_c (x[m,c] * scale[c] + shift[c]) * W[c][o]
@@ -273,6 +332,15 @@ bool launch_convbase_fwd(const float* in, const float* W, const float* bias, flo
 bool launch_convbase_wgrad(const float* in, const float* dy, const float* y, float* dW, float* db, int B, int H, int Wd,
                            int CI, int CO, hipStream_t s) {
   if (CO != 32 || CI > 4) return false;
+  if (9 * CI <= 32) {
+    const int64_t nrows = (int64_t)B * H;
+    int rpw = 1;
+    while (nrows / rpw > 4096) rpw *= 2;            // <= 4096 waves: bounds the float-atomic traffic
+    const int64_t waves = (nrows + rpw - 1) / rpw;
+    hipLaunchKernelGGL(k_convbase_wgrad_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in, dy, y, dW, db, B,
+                       H, Wd, CI, rpw);
+    return true;
+  }
   int64_t M = (int64_t)B * H * Wd;
   int64_t ppb = 512;
   while ((M + ppb - 1) / ppb > 1024) ppb *= 2;
