@@ -47,6 +47,10 @@ void launch_conv_wgrad(const float* big, const float* small, float* dW, float* d
 // big = convT_1x1(small) and dot_out[b,c] = sum_hw big * dot_src, fused when the shape allows
 void launch_conv_t_dot(const float* small, const float* w, float* big, const float* dot_src, float* dot_out,
                        ConvGeom g, hipStream_t s);
+// MobileNetV3 backward pair of a 1x1 C->C conv in one pass (kernels_mfma.hip: k_gemm_dual); false = not covered
+bool launch_gemm_dual_mfma(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
+                           float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
+                           hipStream_t s);
 // ELU backward in place: d *= (y > 0 ? 1 : y + 1)
 void launch_elu_bwd(float* d, const float* y, int64_t n, hipStream_t s);
 

@@ -506,4 +506,219 @@ bool launch_conv_taps_mfma(bool transposed, const float* in, const float* w, con
   return false;
 }
 
+
+// =================================================================================================
+// Dual kernel for the MobileNetV3 backward (layer_blocks.py:594-641 inverted): from ONE staged pair of tiles
+//     Y[M,C]  = X[M,C] . Wt + residual            (T-form 1x1: Wt[k][n] = W[n*C + k], W = Conv2D kernel [ci][co])
+//     dW[ci][co] += sum_m (aux[m,ci] * gate[b,ci]) * X[m,co] ;   db[co] += sum_m X[m,co]
+//     dot_out[b,c] += sum_{m in image b} Y[m,c] * aux[m,c]          (optional: squeeze-excite gate gradient)
+// which are conv2's pair  (dt2 = dout.W2^T, dW2 = (t1*g)^T dout, dg)  and conv0's pair  (da = dt0.W0^T + dout,
+// dW0 = a^T dt0): 3 tensor passes instead of 5 (the separate kernels re-read both operands).
+// LDS tiles are unpadded and XOR-swizzled per 16-byte chunk (chunk' = chunk ^ (row & (C/4-1))): conflict-free for the
+// row-major float4 staging, the k-permuted ds_read_b128 GEMM fragments and the channel-on-lane wgrad reads alike,
+// and 2 x 32 x C floats per wave keep two 4-wave blocks resident per CU.
+// =================================================================================================
+template <int C>
+__global__ void __launch_bounds__(256, 1) k_gemm_dual(const float* __restrict__ X, const float* __restrict__ W,
+                                                      const float* __restrict__ aux, const float* __restrict__ gate,
+                                                      const float* __restrict__ residual, float* __restrict__ Y,
+                                                      float* __restrict__ dW, float* __restrict__ db,
+                                                      float* __restrict__ dot_out, int64_t M, int64_t rows_per_image) {
+  constexpr int KH = C / 2, NT = C / 32, C4 = C / 4, LD = C / 8, RPL = 64 / C4, MASK = C4 - 1;
+  extern __shared__ __attribute__((aligned(16))) float dl[];
+  float* sW = dl;                                         // [C][C]  (Wt[k][n])
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* sX = dl + C * C + wave * 2 * 32 * C;             // this wave's X tile (later: the Y tile)
+  float* sA = sX + 32 * C;                                // this wave's aux tile
+  for (int idx = threadIdx.x; idx < C * C; idx += 256) {
+    int k = idx / C, n = idx % C;
+    sW[idx] = W[(int64_t)n * C + k];
+  }
+  const int i = lane & 31, h = lane >> 5;
+  const int lc4 = lane % C4, lr = lane / C4;
+  const int64_t ntiles = (M + 127) / 128;
+  const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
+  const f32x4* A4 = reinterpret_cast<const f32x4*>(aux);
+  const f32x4* R4 = reinterpret_cast<const f32x4*>(residual);
+  f32x4* Y4 = reinterpret_cast<f32x4*>(Y);
+#define SWZ4(r, c4) ((r) * C4 + ((c4) ^ ((r) & MASK)))                    /* float4 index */
+#define SWZ1(r, c) ((r) * C + ((((c) >> 2) ^ ((r) & MASK)) << 2) + ((c) & 3)) /* float index */
+
+  f32x16 accw[NT][NT];
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw[kt][nt][r] = 0.f;
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+
+  f32x4 stx[LD], sta[LD];
+  auto load_tile = [&](int64_t tile) {
+    const int64_t row0 = tile * 128 + wave * 32;
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+      int64_t row = row0 + j * RPL + lr;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      stx[j] = row < M ? X4[row * C4 + lc4] : z;
+      sta[j] = row < M ? A4[row * C4 + lc4] : z;
+    }
+  };
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  __syncthreads();       // sW staged; below everything is wave-private or read-only
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * 128 + wave * 32;
+    WAVE_LDS_SYNC();
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+      const int r = j * RPL + lr;
+      reinterpret_cast<f32x4*>(sX)[SWZ4(r, lc4)] = stx[j];
+      reinterpret_cast<f32x4*>(sA)[SWZ4(r, lc4)] = sta[j];
+    }
+    WAVE_LDS_SYNC();
+    if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);          // prefetch under the MFMAs
+    // ---- Y tile = X . Wt
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+      const f32x4 a4 = reinterpret_cast<const f32x4*>(sX)[SWZ4(i, h * (C4 / 2) + q)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = h * KH + q * 4 + e;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], sW[k * C + nt * 32 + i], acc[nt], 0, 0, 0);
+      }
+    }
+    // ---- dW += (aux * gate)^T X over the 32 rows of the tile (lane half h: rows 16h .. 16h+15)
+    float gl[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+      gl[kt] = (gate && row0 < M) ? gate[(row0 / rows_per_image) * C + kt * 32 + i] : 1.0f;
+#pragma unroll 4
+    for (int tt = 0; tt < 16; ++tt) {
+      const int r = h * 16 + tt;
+      float a[NT], bq[NT];
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) a[kt] = sA[SWZ1(r, kt * 32 + i)] * gl[kt];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { bq[nt] = sX[SWZ1(r, nt * 32 + i)]; bsum[nt] += bq[nt]; }
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          accw[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], bq[nt], accw[kt][nt], 0, 0, 0);
+    }
+    WAVE_LDS_SYNC();     // X tile fully consumed: it becomes the Y tile
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        sX[SWZ1(rr, nt * 32 + i)] = acc[nt][r];
+      }
+    // the residual tile is fetched only now: the Y accumulators are parked in LDS, so its 32 registers do not
+    // overlap their live range (the kernel sits at the 256-VGPR budget of 2 waves / SIMD)
+    f32x4 res[LD];
+    if (residual) {
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+        int64_t row = row0 + j * RPL + lr;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        res[j] = row < M ? R4[row * C4 + lc4] : z;
+      }
+    }
+    WAVE_LDS_SYNC();
+    f32x4 dsum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+      const int r = j * RPL + lr;
+      int64_t row = row0 + r;
+      f32x4 v = reinterpret_cast<const f32x4*>(sX)[SWZ4(r, lc4)];
+      if (residual) v = v + res[j];
+      if (row < M) {
+        Y4[row * C4 + lc4] = v;
+        if (dot_out) dsum += v * reinterpret_cast<const f32x4*>(sA)[SWZ4(r, lc4)];
+      }
+    }
+    if (dot_out) {
+#pragma unroll
+      for (int off = C4; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dsum[e] += __shfl_xor(dsum[e], off, 64);
+      if (lane < C4 && row0 < M) {
+        float* dst = dot_out + (row0 / rows_per_image) * C + lc4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dst + e, dsum[e]);
+      }
+    }
+  }
+#undef SWZ4
+#undef SWZ1
+  // ---- reduce the 4 waves' dW tiles through LDS, then one coalesced float-atomic set per block
+  __syncthreads();
+  float* red = dl;
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int ci = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            int idx = ci * C + nt * 32 + i;
+            red[idx] = (wv == 0 ? 0.f : red[idx]) + accw[kt][nt][r];
+          }
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < C * C; idx += 256) atomicAdd(&dW[idx], red[idx]);
+  if (db != nullptr) {
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) red[(wave * 2 + h) * C + nt * 32 + i] = bsum[nt];
+    __syncthreads();
+    if (threadIdx.x < C) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[q * C + threadIdx.x];
+      atomicAdd(&db[threadIdx.x], t);
+    }
+  }
+}
+
+template <int C>
+static void run_gemm_dual(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
+                          float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rpi, hipStream_t s) {
+  const size_t lds = (size_t)(C * C + 4 * 2 * 32 * C) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dual<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  int64_t ntiles = (M + 127) / 128;
+  int grid = (int)(ntiles < 512 ? ntiles : 512);          // 256 CUs x (up to) 2 resident blocks
+  hipLaunchKernelGGL((k_gemm_dual<C>), dim3(grid), dim3(256), lds, s, X, W, aux, gate, residual, Y, dW, db, dot_out, M,
+                     rpi);
+}
+
+// conv (1x1, C -> C) backward pair in one pass; false = shape not covered
+bool launch_gemm_dual_mfma(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
+                           float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
+                           hipStream_t s) {
+  if ((gate || dot_out) && (rows_per_image % 32) != 0) return false;
+  if (C == 64) { run_gemm_dual<64>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, s); return true; }
+  if (C == 32) { run_gemm_dual<32>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, s); return true; }
+  return false;
+}
+
 }  // namespace mvae

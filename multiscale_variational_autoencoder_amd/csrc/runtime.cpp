@@ -476,13 +476,23 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   ConvGeom g = geom1x1(B, m.H, m.W, c, c);
   PreOp none{nullptr, nullptr, nullptr};
   float* bufB = acquire(h, sc, s);
+  bool dual2;
   {
-    hipStream_t w = wgrad_begin(h, sc, s);                                             // dout is ready on the chain
-    PreOp gate{m.g, nullptr, nullptr};
-    launch_conv_wgrad(m.t1, dout, G + m.w2, G + m.b2, g, gate, w);                     // dW2 = (t1*g)^T dout, db2
-    wgrad_reads(h, sc, dout, w);
+    ProfScope ps("gemm_dual_b1", 12.0 * B * HW * c, 4.0 * B * HW * c * c, s);
+    launch_zero(sc.dg, (int64_t)B * c, s);
+    // dt2 = dout . W2^T ; dW2 += (t1*g)^T dout ; db2 ; dg = sum_hw dt2 * t1     -- one pass over (dout, t1)
+    dual2 = launch_gemm_dual_mfma(dout, P + m.w2, m.t1, m.g, nullptr, bufB, G + m.w2, G + m.b2, sc.dg, (int64_t)B * HW, HW,
+                                  c, s);
   }
-  launch_conv_t_dot(dout, P + m.w2, bufB, m.t1, sc.dg, g, s);          // dt2 = dout . W2^T ; dg = sum_hw dt2 * t1
+  if (!dual2) {
+    {
+      hipStream_t w = wgrad_begin(h, sc, s);                                           // dout is ready on the chain
+      PreOp gate{m.g, nullptr, nullptr};
+      launch_conv_wgrad(m.t1, dout, G + m.w2, G + m.b2, g, gate, w);                   // dW2 = (t1*g)^T dout, db2
+      wgrad_reads(h, sc, dout, w);
+    }
+    launch_conv_t_dot(dout, P + m.w2, bufB, m.t1, sc.dg, g, s);        // dt2 = dout . W2^T ; dg = sum_hw dt2 * t1
+  }
   // squeeze-excite backward
   launch_gemm_tn(m.xhat, sc.dg, G + m.sw1, G + m.sb1, B, c, c, P + m.gam, P + m.bet, m.ulin, s);
   launch_gemm_nt(sc.dg, P + m.sw1, sc.ds1, B, c, c, m.ulin, 0, s);
@@ -502,12 +512,21 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
     launch_dw_wgrad(m.t0, bufB, G + m.wd, G + m.bd, B, m.H, m.W, c, s);
     launch_dw_bwd_data(bufB, P + m.wd, m.t0, bufC, B, m.H, m.W, c, s);                 // dt0pre
   }
+  bool dual0;
   {
-    hipStream_t w = wgrad_begin(h, sc, s);                                             // dt0pre is ready on the chain
-    launch_conv_wgrad(x, bufC, G + m.w0, G + m.b0, g, none, w);
-    wgrad_reads(h, sc, bufC, w);
+    ProfScope ps("gemm_dual_b3", 16.0 * B * HW * c, 4.0 * B * HW * c * c, s);
+    // da = dt0pre . W0^T + dout ; dW0 += a^T dt0pre ; db0     -- one pass over (dt0pre, a, dout)
+    dual0 = launch_gemm_dual_mfma(bufC, P + m.w0, x, nullptr, dout, bufB, G + m.w0, G + m.b0, nullptr, (int64_t)B * HW, HW,
+                                  c, s);
   }
-  launch_conv_t(bufC, P + m.w0, nullptr, dout, bufB, g, s);                            // da = dt0pre.W0^T + dout
+  if (!dual0) {
+    {
+      hipStream_t w = wgrad_begin(h, sc, s);                                           // dt0pre is ready on the chain
+      launch_conv_wgrad(x, bufC, G + m.w0, G + m.b0, g, none, w);
+      wgrad_reads(h, sc, bufC, w);
+    }
+    launch_conv_t(bufC, P + m.w0, nullptr, dout, bufB, g, s);                          // da = dt0pre.W0^T + dout
+  }
   release(sc, bufC);
   release(sc, dout);
   return bufB;

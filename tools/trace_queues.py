@@ -28,3 +28,11 @@ for t, d in ev:
     if depth > 0: busy += t - last
     depth += d; last = t
 print("any-queue busy %.3f ms" % (busy / 1e6))
+qmain = max(byq, key=lambda q: sum(r['e'] - r['s'] for r in byq[q]))
+agg = collections.defaultdict(lambda: [0, 0])
+for r in byq[qmain]:
+    k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('mvae::', '')[:44]
+    agg[k][0] += r['e'] - r['s']; agg[k][1] += 1
+print("-- busiest queue (scale 0 chain):")
+for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:24]:
+    print("  %-46s n=%3d  %.3f ms  avg %.1f us" % (k, n, t / 1e6, t / n / 1e3))
