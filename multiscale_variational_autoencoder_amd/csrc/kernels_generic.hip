@@ -608,14 +608,18 @@ __global__ void k_gemm_nn(const float* __restrict__ a, const float* __restrict__
     int j = (int)(i % N);
     int64_t b = i / N;
     const float* ap = a + b * K;
-    float acc0 = 0.f, acc1 = 0.f;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     int k = 0;
-    for (; k + 1 < K; k += 2) {
+    // 16 independent loads in flight per trip: these small products are latency-, not throughput-bound
+#pragma unroll 4
+    for (; k + 3 < K; k += 4) {
       acc0 += ap[k] * w[(int64_t)k * N + j];
       acc1 += ap[k + 1] * w[(int64_t)(k + 1) * N + j];
+      acc2 += ap[k + 2] * w[(int64_t)(k + 2) * N + j];
+      acc3 += ap[k + 3] * w[(int64_t)(k + 3) * N + j];
     }
-    if (k < K) acc0 += ap[k] * w[(int64_t)k * N + j];
-    float acc = acc0 + acc1 + (bias ? bias[j] : 0.f);
+    for (; k < K; ++k) acc0 += ap[k] * w[(int64_t)k * N + j];
+    float acc = (acc0 + acc1) + (acc2 + acc3) + (bias ? bias[j] : 0.f);
     if (out_lin) out_lin[i] = acc;
     out[i] = act_apply(acc, act);
   }
@@ -637,8 +641,10 @@ __global__ void k_gemm_nt(const float* __restrict__ a, const float* __restrict__
     float acc = 0.f;
     if (hs_lin) {
       const float* hp = hs_lin + b * N;
+#pragma unroll 8
       for (int j = 0; j < N; ++j) acc += ap[j] * hsig_grad(hp[j]) * wp[j];
     } else {
+#pragma unroll 8
       for (int j = 0; j < N; ++j) acc += ap[j] * wp[j];
     }
     out[i] = accumulate ? out[i] + acc : acc;

@@ -37,6 +37,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn_split(const float* __restrict__
   const float sc = a_scale ? a_scale[k] : 1.f, sf = a_scale ? a_shift[k] : 0.f;
   const int b0 = blockIdx.y * bpc, b1 = min(B, b0 + bpc);
   float acc = 0.f, accb = 0.f;
+#pragma unroll 8
   for (int b = b0; b < b1; ++b) {
     float gv = g[(int64_t)b * N + j];
     if (hs_lin) gv *= hsig_grad_o(hs_lin[(int64_t)b * N + j]);

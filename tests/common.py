@@ -32,6 +32,8 @@ CONFIGS = {
     "c32nb": dict(input_dims=(32, 32, 3), z_dims=[16, 16, 16], encoder=NB, decoder=NB),
     # BASELINE configs 4-5 shrunk to 64x64 / 5 scales for parity runs (same block structure as C256-nb)
     "c64nb": dict(input_dims=(64, 64, 3), z_dims=[16] * 5, encoder=NB, decoder=NB),
+    # BASELINE configs 4-5 (C256-nb), full size: 7 scales from 256x256 down to 4x4
+    "c256nb": dict(input_dims=(256, 256, 3), z_dims=[16] * 7, encoder=NB, decoder=NB),
 }
 COMPILE = dict(learning_rate=0.001, r_loss_factor=1000.0, kl_loss_factor=10.0, clip_norm=1.0)   # notebook cells 5-6
 

@@ -189,6 +189,42 @@ def test_graph_replay_and_streams_match_eager(name, B, monkeypatch):
             assert abs(m3[k] - m1[k]) <= 5.0 * floor, (k, m1[k], m2[k], m3[k])
 
 
+def test_c256nb_full_size_parity_and_training():
+    """BASELINE config 4's model (256x256x3, 7 scales, notebook blocks; fp32 here) at batch 2 against the oracle
+    (ELBO terms + reconstruction + a sample of gradients), then a few optimiser steps at batch 8: finite and
+    decreasing loss.  Exercises the 64-bit indexing / column-strip paths the 32x32 configs never reach."""
+    from oracle.mvae_oracle import Oracle
+    name, B = "c256nb", 2
+    io = make_inputs(name, B)
+    orc = Oracle(oracle_config(name))
+    res, G = orc.loss_and_grads(io["params"], io["state"], io["x"], io["eps"], io["noise"], io["keep"],
+                                COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    eng = _engine(name, 8)
+    eng.set_params(io["params"]); eng.set_state(io["state"])
+    d = {k: eng.to_device(io[k]) for k in ("x", "eps", "noise", "keep")}
+    out = eng.forward(d["x"], True, d["eps"], d["noise"], d["keep"], outputs=("recon", "losses"))
+    eng.backward(COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    losses = out["losses"].cpu().numpy().astype(np.float64)
+    elbo = (COMPILE["r_loss_factor"] * losses[:, 1] + COMPILE["kl_loss_factor"] * losses[:, 2]).mean()
+    assert abs(elbo - res["data_loss"]) / abs(res["data_loss"]) <= TOL_ELBO
+    assert rel_err(losses[:, 3:], res["kl_scale"]) <= TOL_ELBO
+    assert np.abs(out["recon"].cpu().numpy() - res["recon"]).max() <= TOL_RECON_ABS
+    grads = eng.get_grads()
+    rg = reg_grad(io["params"], eng.param_table)
+    gerr = grad_errors({k: grads[k].astype(np.float64) + rg[k] for k in G}, G)
+    zero = structurally_zero(G)        # biases feeding BatchNorm: pure fp32 cancellation noise, 10x looser bound
+    worst = max(((k, v) for k, v in gerr.items() if k not in zero), key=lambda kv: kv[1])
+    assert worst[1] <= TOL_GRAD, worst
+    assert all(gerr[k] <= 10 * TOL_GRAD for k in zero), {k: gerr[k] for k in zero if gerr[k] > 10 * TOL_GRAD}
+    x8 = eng.to_device(np.random.default_rng(2).uniform(0, 255, (8, 256, 256, 3)))
+    vals = []
+    for step in range(6):
+        eng.train_step(x8, 0.01, COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"], 1.0, seed=step)
+        m = eng.metrics()
+        vals.append(1000.0 * m["r_exp"] + 10.0 * m["vae_kl_loss"])
+    assert np.isfinite(vals).all() and vals[-1] < vals[0], vals
+
+
 def test_golden_fixture_tiny():
     """The committed fixture (tests/golden/tiny_case.npz, generated by tests/golden/make_golden.py from the oracle)."""
     f = np.load(os.path.join(ROOT, "tests", "golden", "tiny_case.npz"))
