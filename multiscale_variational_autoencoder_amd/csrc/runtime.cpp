@@ -761,8 +761,14 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   if (const char* v = getenv("MVAE_STREAMS")) h->multi_stream = atoi(v) != 0;
   if (const char* v = getenv("MVAE_WGRAD_STREAMS")) h->wgrad_streams = atoi(v) != 0;
   if (h->wgrad_streams) h->use_graphs = false;
+  // scale 0 (on the caller's stream) is the long pole of every step: the other scales only fill the gaps it leaves,
+  // so their streams get the lowest priority
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  const bool use_prio = getenv("MVAE_STREAM_PRIORITY") ? atoi(getenv("MVAE_STREAM_PRIORITY")) != 0 : true;
   for (int l = 1; l < h->cfg.levels && e == hipSuccess; ++l) {
-    e = hipStreamCreateWithFlags(&h->side[l], hipStreamNonBlocking);
+    e = use_prio ? hipStreamCreateWithPriority(&h->side[l], hipStreamNonBlocking, prio_lo)
+                 : hipStreamCreateWithFlags(&h->side[l], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming);
   }
   for (Scale& sc : h->scales) {
