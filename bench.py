@@ -166,8 +166,17 @@ def main():
         d = kernels[dom]
         bytes_per_launch = d["bytes"] / d["count"]
         dur = d["ms"] * 1e-3 / d["count"]
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this
+        # same command, FETCH doubled per MI355X_MICROARCH.md; tools/pmc_traffic.py), when that kernel was profiled
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            traffic = pmc.get("mvae::" + dom, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         roofline = dict(kernel=dom, bound="hbm", achieved=bytes_per_launch / dur / 1e9, peak=HBM_PEAK / 1e9,
-                        unit="GB/s", frac=bytes_per_launch / dur / HBM_PEAK, traffic=None,
+                        unit="GB/s", frac=bytes_per_launch / dur / HBM_PEAK, traffic=traffic,
                         avg_launch_us=dur * 1e6, launches_per_step=d["count"] / nprof,
                         algorithmic_bytes_per_launch=bytes_per_launch,
                         flop_frac=d["flops"] / d["count"] / dur / FP32_PEAK, share_of_step=d["share"])

@@ -452,7 +452,7 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
   launch_conv_f(x, P + m.w0, P + m.b0, nullptr, m.t0, g, none, ACT_RELU, s);
   bool fused_dw;
   {
-    ProfScope ps("dw_fwd_gap", 8.0 * B * m.H * m.W * c, 20.0 * B * m.H * m.W * c, s);
+    ProfScope ps("k_dw_fwd_ring<true>", 8.0 * B * m.H * m.W * c, 20.0 * B * m.H * m.W * c, s);
     fused_dw = launch_dw_fwd_gap(m.t0, P + m.wd, P + m.bd, m.t1, m.gap, B, m.H, m.W, c, s);
   }
   if (!fused_dw) {
@@ -478,7 +478,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   float* bufB = acquire(h, sc, s);
   bool dual2;
   {
-    ProfScope ps("gemm_dual_b1", 12.0 * B * HW * c, 4.0 * B * HW * c * c, s);
+    ProfScope ps(c == 64 ? "k_gemm_dual<64>" : "k_gemm_dual<32>", 12.0 * B * HW * c, 4.0 * B * HW * c * c, s);
     launch_zero(sc.dg, (int64_t)B * c, s);
     // dt2 = dout . W2^T ; dW2 += (t1*g)^T dout ; db2 ; dg = sum_hw dt2 * t1     -- one pass over (dout, t1)
     dual2 = launch_gemm_dual_mfma(dout, P + m.w2, m.t1, m.g, nullptr, bufB, G + m.w2, G + m.b2, sc.dg, (int64_t)B * HW, HW,
@@ -503,7 +503,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   float* bufC = acquire(h, sc, s);
   bool fused_dw;
   {
-    ProfScope ps("dw_bwd_fused", 16.0 * B * HW * c, 40.0 * B * HW * c, s);
+    ProfScope ps("k_dw_bwd_ring", 16.0 * B * HW * c, 40.0 * B * HW * c, s);
     fused_dw = launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC, G + m.wd, G + m.bd, sc.dw_part, B, m.H,
                                    m.W, c, s);
   }
@@ -514,7 +514,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   }
   bool dual0;
   {
-    ProfScope ps("gemm_dual_b3", 16.0 * B * HW * c, 4.0 * B * HW * c * c, s);
+    ProfScope ps(c == 64 ? "k_gemm_dual<64>" : "k_gemm_dual<32>", 16.0 * B * HW * c, 4.0 * B * HW * c * c, s);
     // da = dt0pre . W0^T + dout ; dW0 += a^T dt0pre ; db0     -- one pass over (dt0pre, a, dout)
     dual0 = launch_gemm_dual_mfma(bufC, P + m.w0, x, nullptr, dout, bufB, G + m.w0, G + m.b0, nullptr, (int64_t)B * HW, HW,
                                   c, s);
