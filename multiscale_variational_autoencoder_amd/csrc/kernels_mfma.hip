@@ -41,7 +41,7 @@ __device__ __forceinline__ float act_apply_m(float v, int act) {
 // block = 4 waves; wave w owns rows [tile*128 + 32w, +32).  Persistent over tiles.
 // =================================================================================================
 template <int K, int N, bool WT>
-__global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, const float* __restrict__ W,
+__global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ X, const float* __restrict__ W,
                                                    const float* __restrict__ bias, const float* __restrict__ residual,
                                                    float* __restrict__ Y, int64_t M, int64_t rows_per_image, PreOp pre,
                                                    int act, const float* __restrict__ dot_src,
@@ -53,15 +53,21 @@ __global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, 
   constexpr int C4 = K / 4, N4 = N / 4;        // float4 chunks per input / output row
   constexpr int LD = K / 8, ST = N / 8;        // float4 loads / stores per lane per 32-row tile
   constexpr int RPL = 64 / C4, RPS = 64 / N4;  // rows covered by one wave-wide float4 load / store
-  __shared__ __attribute__((aligned(16))) float lds[K * N + 4 * 32 * TS];
-  float* sW = lds;
+  __shared__ __attribute__((aligned(16))) float lds[4 * 32 * TS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* sT = lds + K * N + wave * 32 * TS;    // this wave's tile: A operand first, C result afterwards
-  for (int idx = threadIdx.x; idx < K * N; idx += 256) {
-    int k = idx / N, n = idx % N;
-    sW[idx] = WT ? W[(int64_t)n * K + k] : W[idx];
-  }
+  float* sT = lds + wave * 32 * TS;            // this wave's tile: A operand first, C result afterwards
   const int i = lane & 31, h = lane >> 5;
+  // The B operand of every MFMA is a WEIGHT: Wm[k = h*KH + t][n = nt*32 + i] is the same for every tile, so each lane
+  // keeps its KH x NT weights in registers for the whole kernel (64 VGPRs at 64x64) -- no LDS traffic, no waits in
+  // the MFMA phase.
+  float breg[KH][NT];
+#pragma unroll
+  for (int t = 0; t < KH; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int k = h * KH + t, n = nt * 32 + i;
+      breg[t][nt] = WT ? W[(int64_t)n * K + k] : W[(int64_t)k * N + n];
+    }
   const int lc4 = lane % C4, lr = lane / C4;   // load mapping: row = j*RPL + lr, chunk lc4
   const int sc4 = lane % N4, sr = lane / N4;   // store mapping
   const int64_t ntiles = (M + 127) / 128;
@@ -74,30 +80,37 @@ __global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, 
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   if (pre.scale) { psc = reinterpret_cast<const f32x4*>(pre.scale)[lc4]; psh = reinterpret_cast<const f32x4*>(pre.shift)[lc4]; }
 
+  // Prefetch = RAW loads only, all issued back to back (pre-ops are applied when the tile is written to LDS, a whole
+  // MFMA phase later): anything computed between the loads makes hipcc wait for each load before issuing the next.
+  // The squeeze-excite gate is constant over a tile (launcher: rows_per_image % 32 == 0): one 16-byte load per tile.
   f32x4 stage[LD];
+  f32x4 gstage = {1.f, 1.f, 1.f, 1.f};
+  const uint32_t rpi32 = (uint32_t)rows_per_image;
   auto load_tile = [&](int64_t tile) {
     const int64_t row0 = tile * 128 + wave * 32;
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
       int64_t row = row0 + j * RPL + lr;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < M) {
-        v = X4[row * C4 + lc4];
-        if (pre.scale) v = v * psc + psh;
-        if (pre.gate) v = v * reinterpret_cast<const f32x4*>(pre.gate)[(row / rows_per_image) * C4 + lc4];
-      }
-      stage[j] = v;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      stage[j] = row < M ? X4[row * C4 + lc4] : z;
     }
+    if (pre.gate && row0 < M)
+      gstage = reinterpret_cast<const f32x4*>(pre.gate)[(int64_t)((uint32_t)row0 / rpi32) * C4 + lc4];
   };
 
   int64_t tile = blockIdx.x;
   if (tile < ntiles) load_tile(tile);
-  __syncthreads();       // sW staged; everything below is wave-private (sT) or read-only (sW)
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < ntiles; tile += gridDim.x) {            // everything below is wave-private: no block barrier
     const int64_t row0 = tile * 128 + wave * 32;
     WAVE_LDS_SYNC();     // the previous tile's C read-back is done
 #pragma unroll
-    for (int j = 0; j < LD; ++j) *reinterpret_cast<f32x4*>(&sT[(j * RPL + lr) * TS + lc4 * 4]) = stage[j];
+    for (int j = 0; j < LD; ++j) {
+      f32x4 v = stage[j];
+      if (pre.scale) v = v * psc + psh;
+      if (pre.gate) v = v * gstage;
+      if (row0 + j * RPL + lr >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&sT[(j * RPL + lr) * TS + lc4 * 4]) = v;
+    }
     WAVE_LDS_SYNC();
     if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);    // prefetch under the MFMAs
     f32x4 res[ST];
@@ -114,17 +127,16 @@ __global__ void __launch_bounds__(256) k_gemm_rows(const float* __restrict__ X, 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    f32x4 afr[KH / 4];
 #pragma unroll
-    for (int q = 0; q < KH / 4; ++q) {
-      f32x4 a4 = *reinterpret_cast<const f32x4*>(&sT[i * TS + h * KH + q * 4]);
+    for (int q = 0; q < KH / 4; ++q) afr[q] = *reinterpret_cast<const f32x4*>(&sT[i * TS + h * KH + q * 4]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = h * KH + q * 4 + e;
+    for (int q = 0; q < KH / 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], sW[k * N + nt * 32 + i], acc[nt], 0, 0, 0);
-      }
-    }
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[q * 4 + e][nt], acc[nt], 0, 0, 0);
     WAVE_LDS_SYNC();     // every lane's A fragments are consumed: the tile buffer becomes the C tile
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -168,7 +180,7 @@ static void run_gemm_rows(const float* X, const float* W, const float* bias, con
                           int64_t M, int64_t rows_per_image, PreOp pre, int act, const float* dot_src, float* dot_out,
                           hipStream_t s) {
   int64_t ntiles = (M + 127) / 128;
-  int grid = (int)(ntiles < 768 ? ntiles : 768);     // 256 CUs x 3 resident workgroups
+  int grid = (int)(ntiles < 512 ? ntiles : 512);     // 256 CUs x 2 resident workgroups (register-limited)
   hipLaunchKernelGGL((k_gemm_rows<K, N, WT>), dim3(grid), dim3(256), 0, s, X, W, bias, residual, Y, M, rows_per_image,
                      pre, act, dot_src, dot_out);
 }
@@ -178,7 +190,7 @@ bool launch_conv1x1_mfma(bool transposed, const float* in, const float* w, const
                          float* out, const ConvGeom& g, PreOp pre, int act, const float* dot_src, float* dot_out,
                          hipStream_t s) {
   if (g.KH != 1 || g.KW != 1 || g.SH != 1 || g.SW != 1) return false;
-  if (dot_src && (((int64_t)g.IH * g.IW) % 32) != 0) return false;
+  if ((dot_src || pre.gate) && (((int64_t)g.IH * g.IW) % 32) != 0) return false;
   const int K = transposed ? g.CO : g.CI, N = transposed ? g.CI : g.CO;
   const int64_t M = (int64_t)g.B * g.IH * g.IW, rpi = (int64_t)g.IH * g.IW;
 #define MVAE_GR(KK, NN)                                                                                   \
@@ -283,19 +295,26 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_rows(const float* __restrict__
     for (int j = 0; j < LG; ++j) *reinterpret_cast<f32x4*>(&sG[(j * RPG + gr) * CO + gc4 * 4]) = pg[j];
     WAVE_LDS_SYNC();
     if (row0 + 4 * R < m_end) load_tile(row0 + 4 * R);       // prefetch under the MFMAs
+    // all operands of the tile are read from LDS up front (R/2 * (KT+NT) registers): the MFMAs then issue back to
+    // back instead of each waiting for its own ds_read
+    float av[R / 2][KT], bv[R / 2][NT];
 #pragma unroll
     for (int tt = 0; tt < R / 2; ++tt) {
       const int r = h * (R / 2) + tt;       // lane half h sums rows [8h, 8h+8) of the tile
-      float a[KT], bq[NT];
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) a[kt] = sX[r * CI + kt * 32 + i];
+      for (int kt = 0; kt < KT; ++kt) av[tt][kt] = sX[r * CI + kt * 32 + i];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) { bq[nt] = sG[r * CO + nt * 32 + i]; bsum[nt] += bq[nt]; }
+      for (int nt = 0; nt < NT; ++nt) bv[tt][nt] = sG[r * CO + nt * 32 + i];
+    }
+#pragma unroll
+    for (int tt = 0; tt < R / 2; ++tt) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bsum[nt] += bv[tt][nt];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], bq[nt], acc[kt][nt], 0, 0, 0);
+          acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt][kt], bv[tt][nt], acc[kt][nt], 0, 0, 0);
     }
   }
   // ---- reduce the 4 waves through LDS, then ONE set of coalesced float atomics per block
@@ -414,13 +433,19 @@ __global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in,
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
+  constexpr int WPT = KC * NC / 256;                     // weights per thread per tap
   auto stage_w = [&](int it, int buf) {
     const int kh = kh0 + (it / nkw) * khs, kw = kw0 + (it % nkw) * kws;
     const float* wt = W + (int64_t)(kh * g.KW + kw) * KC * NC;
-    for (int idx = threadIdx.x; idx < KC * NC; idx += 256) {
+    float tmp[WPT];                                      // all loads first, then the LDS writes
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) tmp[u] = wt[threadIdx.x + u * 256];
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+      const int idx = threadIdx.x + u * 256;
       // sW[k][n]; F: W[tap][k][n] as stored; T: W[tap][n][k]
-      if (TFORM) { int n = idx / KC, k = idx % KC; sW[buf][k * NC + n] = wt[idx]; }
-      else sW[buf][idx] = wt[idx];
+      if (TFORM) { int n = idx / KC, k = idx % KC; sW[buf][k * NC + n] = tmp[u]; }
+      else sW[buf][idx] = tmp[u];
     }
   };
   f32x4 a_next[Q];
@@ -454,15 +479,18 @@ __global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in,
     for (int q = 0; q < Q; ++q) a[q] = a_next[q];
     if (it + 1 < ntaps) { stage_w(it + 1, (it + 1) & 1); load_a(it + 1); }
     const float* w = sW[it & 1];
+    float bw[KHF][NT];                                   // this tap's weight fragment: all LDS reads up front
+#pragma unroll
+    for (int t = 0; t < KHF; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bw[t][nt] = w[(h * KHF + t) * NC + nt * 32 + i];
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = h * KHF + q * 4 + e;
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], w[k * NC + nt * 32 + i], acc[nt], 0, 0, 0);
-      }
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], bw[q * 4 + e][nt], acc[nt], 0, 0, 0);
   }
   __syncthreads();     // sOff visible (also when ntaps == 0)
 #pragma unroll
@@ -526,15 +554,15 @@ __global__ void __launch_bounds__(256, 1) k_gemm_dual(const float* __restrict__ 
                                                       float* __restrict__ dot_out, int64_t M, int64_t rows_per_image) {
   constexpr int KH = C / 2, NT = C / 32, C4 = C / 4, LD = C / 8, RPL = 64 / C4, MASK = C4 - 1;
   extern __shared__ __attribute__((aligned(16))) float dl[];
-  float* sW = dl;                                         // [C][C]  (Wt[k][n])
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* sX = dl + C * C + wave * 2 * 32 * C;             // this wave's X tile (later: the Y tile)
+  float* sX = dl + wave * 2 * 32 * C;                     // this wave's X tile (later: the Y tile)
   float* sA = sX + 32 * C;                                // this wave's aux tile
-  for (int idx = threadIdx.x; idx < C * C; idx += 256) {
-    int k = idx / C, n = idx % C;
-    sW[idx] = W[(int64_t)n * C + k];
-  }
   const int i = lane & 31, h = lane >> 5;
+  float breg[KH][NT];                                     // Wt[k = h*KH + t][n = nt*32 + i], resident in registers
+#pragma unroll
+  for (int t = 0; t < KH; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) breg[t][nt] = W[(int64_t)(nt * 32 + i) * C + h * KH + t];
   const int lc4 = lane % C4, lr = lane / C4;
   const int64_t ntiles = (M + 127) / 128;
   const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
@@ -568,8 +596,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_dual(const float* __restrict__ 
   };
   int64_t tile = blockIdx.x;
   if (tile < ntiles) load_tile(tile);
-  __syncthreads();       // sW staged; below everything is wave-private or read-only
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < ntiles; tile += gridDim.x) {             // the tile loop is wave-private: no block barrier
     const int64_t row0 = tile * 128 + wave * 32;
     WAVE_LDS_SYNC();
 #pragma unroll
@@ -586,35 +613,43 @@ __global__ void __launch_bounds__(256, 1) k_gemm_dual(const float* __restrict__ 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    f32x4 afr[KH / 4];
 #pragma unroll
-    for (int q = 0; q < KH / 4; ++q) {
-      const f32x4 a4 = reinterpret_cast<const f32x4*>(sX)[SWZ4(i, h * (C4 / 2) + q)];
+    for (int q = 0; q < KH / 4; ++q) afr[q] = reinterpret_cast<const f32x4*>(sX)[SWZ4(i, h * (C4 / 2) + q)];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = h * KH + q * 4 + e;
+    for (int q = 0; q < KH / 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], sW[k * C + nt * 32 + i], acc[nt], 0, 0, 0);
-      }
-    }
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[q * 4 + e][nt], acc[nt], 0, 0, 0);
     // ---- dW += (aux * gate)^T X over the 32 rows of the tile (lane half h: rows 16h .. 16h+15)
     float gl[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
       gl[kt] = (gate && row0 < M) ? gate[(row0 / rows_per_image) * C + kt * 32 + i] : 1.0f;
-#pragma unroll 4
-    for (int tt = 0; tt < 16; ++tt) {
-      const int r = h * 16 + tt;
-      float a[NT], bq[NT];
+    // operands in two batches of 8 row-pairs, each read from LDS before its MFMAs are issued
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt) a[kt] = sA[SWZ1(r, kt * 32 + i)] * gl[kt];
+    for (int half = 0; half < 2; ++half) {
+      float av[8][NT], bv[8][NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) { bq[nt] = sX[SWZ1(r, nt * 32 + i)]; bsum[nt] += bq[nt]; }
+      for (int tt = 0; tt < 8; ++tt) {
+        const int r = h * 16 + half * 8 + tt;
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
+        for (int kt = 0; kt < NT; ++kt) av[tt][kt] = sA[SWZ1(r, kt * 32 + i)] * gl[kt];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          accw[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kt], bq[nt], accw[kt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) bv[tt][nt] = sX[SWZ1(r, nt * 32 + i)];
+      }
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bsum[nt] += bv[tt][nt];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            accw[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt][kt], bv[tt][nt], accw[kt][nt], 0, 0, 0);
+      }
     }
     WAVE_LDS_SYNC();     // X tile fully consumed: it becomes the Y tile
 #pragma unroll
@@ -698,7 +733,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_dual(const float* __restrict__ 
 template <int C>
 static void run_gemm_dual(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
                           float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rpi, hipStream_t s) {
-  const size_t lds = (size_t)(C * C + 4 * 2 * 32 * C) * sizeof(float);
+  const size_t lds = (size_t)(4 * 2 * 32 * C) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dual<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
