@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
     f32x4 afr[KH / 4];
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q) afr[q] = *reinterpret_cast<const f32x4*>(&sT[i * TS + h * KH + q * 4]);
+    __builtin_amdgcn_sched_barrier(0);   // keep all fragment reads in flight ahead of the MFMAs (progressive lgkmcnt)
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q)
 #pragma unroll
@@ -306,6 +307,7 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_rows(const float* __restrict__
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bv[tt][nt] = sG[r * CO + nt * 32 + i];
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tt = 0; tt < R / 2; ++tt) {
 #pragma unroll
@@ -479,18 +481,15 @@ __global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in,
     for (int q = 0; q < Q; ++q) a[q] = a_next[q];
     if (it + 1 < ntaps) { stage_w(it + 1, (it + 1) & 1); load_a(it + 1); }
     const float* w = sW[it & 1];
-    float bw[KHF][NT];                                   // this tap's weight fragment: all LDS reads up front
-#pragma unroll
-    for (int t = 0; t < KHF; ++t)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bw[t][nt] = w[(h * KHF + t) * NC + nt * 32 + i];
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e) {
+        const int k = h * KHF + q * 4 + e;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], bw[q * 4 + e][nt], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], w[k * NC + nt * 32 + i], acc[nt], 0, 0, 0);
+      }
   }
   __syncthreads();     // sOff visible (also when ntaps == 0)
 #pragma unroll
@@ -616,6 +615,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_dual(const float* __restrict__ 
     f32x4 afr[KH / 4];
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q) afr[q] = reinterpret_cast<const f32x4*>(sX)[SWZ4(i, h * (C4 / 2) + q)];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q)
 #pragma unroll
@@ -623,6 +623,16 @@ __global__ void __launch_bounds__(256, 1) k_gemm_dual(const float* __restrict__ 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[q * 4 + e][nt], acc[nt], 0, 0, 0);
+    // the residual tile is fetched here, a whole MFMA phase ahead of its use (1 wave / SIMD: 512 registers)
+    f32x4 res[LD];
+    if (residual) {
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+        int64_t row = row0 + j * RPL + lr;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        res[j] = row < M ? R4[row * C4 + lc4] : z;
+      }
+    }
     // ---- dW += (aux * gate)^T X over the 32 rows of the tile (lane half h: rows 16h .. 16h+15)
     float gl[NT];
 #pragma unroll
@@ -640,6 +650,7 @@ __global__ void __launch_bounds__(256, 1) k_gemm_dual(const float* __restrict__ 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bv[tt][nt] = sX[SWZ1(r, nt * 32 + i)];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tt = 0; tt < 8; ++tt) {
 #pragma unroll
@@ -659,17 +670,6 @@ __global__ void __launch_bounds__(256, 1) k_gemm_dual(const float* __restrict__ 
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
         sX[SWZ1(rr, nt * 32 + i)] = acc[nt][r];
       }
-    // the residual tile is fetched only now: the Y accumulators are parked in LDS, so its 32 registers do not
-    // overlap their live range (the kernel sits at the 256-VGPR budget of 2 waves / SIMD)
-    f32x4 res[LD];
-    if (residual) {
-#pragma unroll
-      for (int j = 0; j < LD; ++j) {
-        int64_t row = row0 + j * RPL + lr;
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        res[j] = row < M ? R4[row * C4 + lc4] : z;
-      }
-    }
     WAVE_LDS_SYNC();
     f32x4 dsum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

