@@ -36,20 +36,33 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const f32x4* __restrict__ i
   f32x4* oimg = out + (int64_t)b * g.H * g.W * g.C4;
   const int row_items = XSP * g.C4;
 
-  auto load_row = [&](int y) {                        // global row y (with column halo) -> ring slot y & 3
-    for (int t = threadIdx.x; t < row_items; t += 256) {
-      const int xs = t / g.C4, cc = t % g.C4;
-      const int x = x0 - 1 + xs;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (x >= 0 && x < g.W) v = img[((int64_t)y * g.W + x) * g.C4 + cc];
-      RING(y & 3, xs, cc) = v;
+  // rows are fetched into registers one iteration before they are stored to the ring (see k_dw_bwd_ring)
+  f32x4 rv[3];
+  auto fetch_row = [&](int y) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int t = threadIdx.x + 256 * u;
+      rv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < row_items) {
+        const int x = x0 - 1 + t / g.C4;
+        if (x >= 0 && x < g.W) rv[u] = img[((int64_t)y * g.W + x) * g.C4 + c4];
+      }
+    }
+  };
+  auto store_row = [&](int y) {                       // row y (with column halo) -> ring slot y & 3
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int t = threadIdx.x + 256 * u;
+      if (t < row_items) RING(y & 3, t / g.C4, c4) = rv[u];
     }
   };
   f32x4 gsum[2];
   gsum[0] = gsum[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  load_row(0);
+  fetch_row(0); store_row(0);
+  if (g.H > 1) fetch_row(1);
   for (int y = 0; y < g.H; ++y) {
-    if (y + 1 < g.H) load_row(y + 1);
+    if (y + 1 < g.H) store_row(y + 1);
+    if (y + 2 < g.H) fetch_row(y + 2);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -119,24 +132,41 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
     const int b = item / nseg, seg = item % nseg;
     const int ya = seg * RS, yb = min(g.H, ya + RS);
     const int64_t ioff = (int64_t)b * g.H * g.W * g.C4;
-    auto load_row = [&](int y) {                      // d1 row y (with column halo) -> ring slot y & 3
-      for (int t = threadIdx.x; t < row_items; t += 256) {
-        const int xs = t / g.C4, cc = t % g.C4;
-        const int x = x0 - 1 + xs;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (x >= 0 && x < g.W) {
-          const int64_t o = ioff + ((int64_t)y * g.W + x) * g.C4 + cc;
-          const f32x4 d = dt2[o], a = t1[o];
-          const f32x4 gg = gate[(int64_t)b * g.C4 + cc], dg = dgap[(int64_t)b * g.C4 + cc] * inv_hw;
+    // a row of d1 is fetched in two steps: raw loads into registers (issued two rows ahead), and -- one iteration
+    // later, after the compute of the current row -- the gate/ReLU arithmetic and the LDS store.  row_items <= 3*256.
+    f32x4 rd[3], ra[3];
+    const f32x4 gg_c = gate[(int64_t)b * g.C4 + c4];       // (row_items % C4 == 0 and 256 % C4 == 0: cc == c4)
+    const f32x4 dg_c = dgap[(int64_t)b * g.C4 + c4] * inv_hw;
+    auto fetch_row = [&](int y) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = a[q] > 0.f ? d[q] * gg[q] + dg[q] : 0.f;
+      for (int u = 0; u < 3; ++u) {
+        const int t = threadIdx.x + 256 * u;
+        rd[u] = ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < row_items) {
+          const int x = x0 - 1 + t / g.C4;
+          if (x >= 0 && x < g.W) {
+            const int64_t o = ioff + ((int64_t)y * g.W + x) * g.C4 + c4;
+            rd[u] = dt2[o]; ra[u] = t1[o];
+          }
         }
-        RING(y & 3, xs, cc) = v;
+      }
+    };
+    auto store_row = [&](int y) {                     // d1 row y (with column halo) -> ring slot y & 3
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int t = threadIdx.x + 256 * u;
+        if (t < row_items) {
+          f32x4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = ra[u][q] > 0.f ? rd[u][q] * gg_c[q] + dg_c[q] : 0.f;
+          RING(y & 3, t / g.C4, c4) = v;
+        }
       }
     };
     __syncthreads();                                  // previous item's ring reads are done
-    if (ya > 0) load_row(ya - 1);
-    load_row(ya);
+    if (ya > 0) { fetch_row(ya - 1); store_row(ya - 1); }
+    fetch_row(ya); store_row(ya);
+    if (ya + 1 < g.H) fetch_row(ya + 1);              // in flight across the first iteration
     for (int y = ya; y < yb; ++y) {
       // t0 of this row is independent of the ring: issue it before the barrier so both latencies overlap
       const int64_t o0 = ioff + ((int64_t)y * g.W + x0 + xl0) * g.C4 + c4;
@@ -144,7 +174,8 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
       f32x4 tv[2];
       tv[0] = has0 ? t0[o0] : f32x4{0.f, 0.f, 0.f, 0.f};
       tv[1] = has1 ? t0[o1] : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (y + 1 < g.H) load_row(y + 1);
+      if (y + 1 < g.H) store_row(y + 1);              // fetched during the previous iteration
+      if (y + 2 < g.H && y + 1 < yb) fetch_row(y + 2);
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
