@@ -183,6 +183,9 @@ bool launch_dense_expand(const float* z, const float* W, const float* bias, floa
                          hipStream_t s);
 bool launch_dense_wgrad_mu_lv(const float* flat, const float* dmu, const float* dlv, float* dWmu, float* dWlv,
                               float* dbmu, float* dblv, int B, int K, int Z, hipStream_t s);
+// squeeze-excite backward pair in one launch: dW += a'^T g' (+ db) and dx = g' W^T   (kernels_opt.hip)
+void launch_se_pair(const float* a, const float* g, const float* W, float* dW, float* db, float* dx, int B, int K, int N,
+                    const float* a_scale, const float* a_shift, const float* hs_lin, hipStream_t s);
 void launch_add_vec2(float* o0, const float* a0, float* o1, const float* a1, int n, hipStream_t s);
 
 }  // namespace mvae

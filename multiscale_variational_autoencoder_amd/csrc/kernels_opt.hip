@@ -222,6 +222,64 @@ __global__ void __launch_bounds__(256) k_dw_wgrad_slide(const float* __restrict_
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Squeeze-excite backward pair in ONE launch (the two products share g' and are independent):
+//   blocks [0, tn_blocks):  dW[k,n] += sum_b a'[b,k] g'[b,n] ; db[n] += sum_b g'[b,n]     (batch split in `chunks`)
+//   remaining blocks     :  dx[b,k]  = sum_n g'[b,n] W[k,n]
+// with a' = a*a_scale+a_shift (folded BatchNorm output) and g' = g * hsig'(hs_lin) when hs_lin != null.
+// -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_se_pair(const float* __restrict__ a, const float* __restrict__ g,
+                                                 const float* __restrict__ W, float* __restrict__ dW,
+                                                 float* __restrict__ db, float* __restrict__ dx, int B, int K, int N,
+                                                 const float* __restrict__ a_scale, const float* __restrict__ a_shift,
+                                                 const float* __restrict__ hs_lin, int bpc, int chunks, int tn_blocks) {
+  if ((int)blockIdx.x < tn_blocks) {
+    const int bx = blockIdx.x / chunks, by = blockIdx.x % chunks;
+    const int64_t i = (int64_t)bx * 256 + threadIdx.x;
+    if (i >= (int64_t)K * N) return;
+    const int j = (int)(i % N), k = (int)(i / N);
+    const float sc = a_scale ? a_scale[k] : 1.f, sf = a_scale ? a_shift[k] : 0.f;
+    const int b0 = by * bpc, b1 = min(B, b0 + bpc);
+    float acc = 0.f, accb = 0.f;
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) {
+      float gv = g[(int64_t)b * N + j];
+      if (hs_lin) gv *= hsig_grad_o(hs_lin[(int64_t)b * N + j]);
+      acc += (a[(int64_t)b * K + k] * sc + sf) * gv;
+      accb += gv;
+    }
+    atomicAdd(&dW[i], acc);
+    if (k == 0 && db) atomicAdd(&db[j], accb);
+  } else {
+    const int64_t i = (int64_t)(blockIdx.x - tn_blocks) * 256 + threadIdx.x;
+    if (i >= (int64_t)B * K) return;
+    const int k = (int)(i % K);
+    const int64_t b = i / K;
+    const float* gp = g + b * N;
+    const float* wp = W + (int64_t)k * N;
+    float acc = 0.f;
+    if (hs_lin) {
+      const float* hp = hs_lin + b * N;
+#pragma unroll 8
+      for (int j = 0; j < N; ++j) acc += gp[j] * hsig_grad_o(hp[j]) * wp[j];
+    } else {
+#pragma unroll 8
+      for (int j = 0; j < N; ++j) acc += gp[j] * wp[j];
+    }
+    dx[i] = acc;
+  }
+}
+void launch_se_pair(const float* a, const float* g, const float* W, float* dW, float* db, float* dx, int B, int K, int N,
+                    const float* a_scale, const float* a_shift, const float* hs_lin, hipStream_t s) {
+  int chunks = B >= 256 ? 16 : (B >= 32 ? 4 : 1);
+  int bpc = (B + chunks - 1) / chunks;
+  chunks = (B + bpc - 1) / bpc;
+  const int tn_blocks = (int)(((int64_t)K * N + 255) / 256) * chunks;
+  const int nt_blocks = (int)(((int64_t)B * K + 255) / 256);
+  hipLaunchKernelGGL(k_se_pair, dim3(tn_blocks + nt_blocks), dim3(256), 0, s, a, g, W, dW, db, dx, B, K, N, a_scale,
+                     a_shift, hs_lin, bpc, chunks, tn_blocks);
+}
+
 // ---- launchers: return false when the shape is not covered ------------------------------------------------
 bool launch_gemm_tn_opt(const float* a, const float* g, float* dW, float* db, int B, int K, int N,
                         const float* a_scale, const float* a_shift, const float* hs_lin, hipStream_t s) {

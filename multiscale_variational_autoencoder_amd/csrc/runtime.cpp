@@ -494,11 +494,17 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
     launch_conv_t_dot(dout, P + m.w2, bufB, m.t1, sc.dg, g, s);        // dt2 = dout . W2^T ; dg = sum_hw dt2 * t1
   }
   // squeeze-excite backward
-  launch_gemm_tn(m.xhat, sc.dg, G + m.sw1, G + m.sb1, B, c, c, P + m.gam, P + m.bet, m.ulin, s);
-  launch_gemm_nt(sc.dg, P + m.sw1, sc.ds1, B, c, c, m.ulin, 0, s);
+  {
+    ProfScope ps("k_se_pair", 16.0 * B * c, 4.0 * B * c * c, s);
+    // du = dg * hsig'(u):  dW1 += s1^T du, db1 += sum du  and  ds1 = du W1^T   (s1 = gamma*xhat + beta)
+    launch_se_pair(m.xhat, sc.dg, P + m.sw1, G + m.sw1, G + m.sb1, sc.ds1, B, c, c, P + m.gam, P + m.bet, m.ulin, s);
+  }
   launch_bn1d_bwd(sc.ds1, m.xhat, m.invstd, P + m.gam, m.s0, sc.dv, G + m.gam, G + m.bet, B, c, s);
-  launch_gemm_tn(m.gap, sc.dv, G + m.sw0, G + m.sb0, B, c, c, nullptr, nullptr, nullptr, s);
-  launch_gemm_nt(sc.dv, P + m.sw0, sc.dgap, B, c, c, nullptr, 0, s);
+  {
+    ProfScope ps("k_se_pair", 16.0 * B * c, 4.0 * B * c * c, s);
+    // dW0 += gap^T dv, db0 += sum dv  and  dgap = dv W0^T
+    launch_se_pair(m.gap, sc.dv, P + m.sw0, G + m.sw0, G + m.sb0, sc.dgap, B, c, c, nullptr, nullptr, nullptr, s);
+  }
   // through the gate multiply, the global average pool and the depthwise ReLU
   float* bufC = acquire(h, sc, s);
   bool fused_dw;
