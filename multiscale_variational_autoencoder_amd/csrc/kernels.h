@@ -48,9 +48,21 @@ void launch_conv_wgrad(const float* big, const float* small, float* dW, float* d
 void launch_conv_t_dot(const float* small, const float* w, float* big, const float* dot_src, float* dot_out,
                        ConvGeom g, hipStream_t s);
 // MobileNetV3 backward pair of a 1x1 C->C conv in one pass (kernels_mfma.hip: k_gemm_dual); false = not covered
+// Gradient slots: float atomics into a footprint of a few KB from hundreds of blocks run far below the chip's atomic
+// rate (MI355X_MICROARCH.md, Global float atomics: "contention"), so small weight gradients are accumulated into
+// n copies of the gradient arena (block b -> copy b % n) which k_slot_sum folds into the arena at the end of backward.
+struct GradSlots {
+  float* base = nullptr;        // n copies, `stride` floats apart, each laid out like the gradient arena
+  const float* gbase = nullptr; // the gradient arena itself
+  int64_t stride = 0;
+  int n = 0;                    // 0 = accumulate straight into the arena
+  float* at(float* g) const { return (n && g) ? base + (g - gbase) : g; }
+  int count() const { return n ? n : 1; }
+};
+void launch_slot_sum(float* g, const float* slots, int64_t elems, int64_t stride, int n, hipStream_t s);
 bool launch_gemm_dual_mfma(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
                            float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
-                           hipStream_t s);
+                           GradSlots slots, hipStream_t s);
 // ELU backward in place: d *= (y > 0 ? 1 : y + 1)
 void launch_elu_bwd(float* d, const float* y, int64_t n, hipStream_t s);
 
@@ -186,6 +198,7 @@ bool launch_dense_wgrad_mu_lv(const float* flat, const float* dmu, const float* 
 // squeeze-excite backward pair in one launch: dW += a'^T g' (+ db) and dx = g' W^T   (kernels_opt.hip)
 void launch_se_pair(const float* a, const float* g, const float* W, float* dW, float* db, float* dx, int B, int K, int N,
                     const float* a_scale, const float* a_shift, const float* hs_lin, hipStream_t s);
+bool launch_dense_wgrad_dec(const float* z, const float* dy, float* dW, float* db, int B, int Z, int N, hipStream_t s);
 void launch_add_vec2(float* o0, const float* a0, float* o1, const float* a1, int n, hipStream_t s);
 
 }  // namespace mvae

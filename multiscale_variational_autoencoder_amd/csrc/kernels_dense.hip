@@ -186,14 +186,28 @@ __global__ void __launch_bounds__(256) k_dense_wgrad_mfma(const float* __restric
   float bsum = 0.f;
   const int per = ((B + 7) / 8) * 2;                 // rows per wave, even
   const int bb = wave * per, be = min(B, bb + per);
-#pragma unroll 8
-  for (int b = bb; b < be; b += 2) {
-    const int row = b + h;
-    const bool rv = row < be;
-    const float a = (rv && kv) ? flat[(int64_t)row * K + k0 + i] : 0.f;
-    const float g = (rv && jv) ? gsrc[(int64_t)row * Z + jx] : 0.f;
-    bsum += g;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, g, acc, 0, 0, 0);
+  // unconditional (clamped) loads, masked by multiplication: the compiler can then issue a whole unrolled batch of
+  // loads ahead of its MFMAs instead of one exec-masked load -> wait -> MFMA chain per row pair
+  const float* pa = flat + (kv ? k0 + i : 0);
+  const float* pg = gsrc + (jv ? jx : 0);
+  const float ma = kv ? 1.f : 0.f, mg = jv ? 1.f : 0.f;
+  for (int b = bb; b < be; b += 16) {                // 8 row pairs per trip, all 16 loads issued before the MFMAs
+    float a[8], g[8], rm[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = b + 2 * u + h;
+      rm[u] = row < be ? 1.f : 0.f;
+      const int rc = row < be ? row : bb;
+      a[u] = pa[(int64_t)rc * K];
+      g[u] = pg[(int64_t)rc * Z];
+    }
+    __builtin_amdgcn_sched_barrier(0);               // raw loads above, every use below
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float gv = g[u] * (mg * rm[u]);
+      bsum += gv;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u] * (ma * rm[u]), gv, acc, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
@@ -209,6 +223,59 @@ __global__ void __launch_bounds__(256) k_dense_wgrad_mfma(const float* __restric
       if (k < K) dW[(int64_t)k * Z + jx] += t;
     }
     if (blockIdx.x == 0 && h == 0) (i < Z ? db1 : db2)[jx] += redb[0][i] + redb[1][i] + redb[2][i] + redb[3][i];
+  }
+}
+
+// decoder Dense weight gradient on the MFMA: dW[k][n] += sum_b z[b,k] dy[b,n] (k < Z <= 32), db[n] += sum_b dy[b,n].
+// block = one 32-wide slice of N; its 4 waves split the batch; D[i = k][j = n]; plain stores (the block owns its slice).
+__global__ void __launch_bounds__(256) k_dense_wgrad_mfma_t(const float* __restrict__ z, const float* __restrict__ dy,
+                                                            float* __restrict__ dW, float* __restrict__ db, int B,
+                                                            int Z, int N) {
+  __shared__ float red[4][16][64];
+  __shared__ float redb[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 32;
+  const int i = lane & 31, h = lane >> 5;
+  const bool kv = i < Z, nv = n0 + i < N;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  const int per = ((B + 7) / 8) * 2;
+  const int bb = wave * per, be = min(B, bb + per);
+  const float* pa = z + (kv ? i : 0);
+  const float* pg = dy + (nv ? n0 + i : 0);
+  const float ma = kv ? 1.f : 0.f, mg = nv ? 1.f : 0.f;
+  for (int b = bb; b < be; b += 16) {                // clamped loads + multiplicative masks: see k_dense_wgrad_mfma
+    float a[8], g[8], rm[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = b + 2 * u + h;
+      rm[u] = row < be ? 1.f : 0.f;
+      const int rc = row < be ? row : bb;
+      a[u] = pa[(int64_t)rc * Z];
+      g[u] = pg[(int64_t)rc * N];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float gv = g[u] * (mg * rm[u]);
+      bsum += gv;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u] * (ma * rm[u]), gv, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (h == 0) redb[wave][i] = bsum;
+  __syncthreads();
+  if (wave == 0 && nv) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (k < Z) dW[(int64_t)k * N + n0 + i] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+    }
+    if (h == 0) db[n0 + i] += redb[0][i] + redb[1][i] + redb[2][i] + redb[3][i];
   }
 }
 
@@ -264,6 +331,13 @@ bool launch_dense_wgrad_mu_lv(const float* flat, const float* dmu, const float* 
   if (bpc < 1) bpc = 1;
   hipLaunchKernelGGL(k_outer_wide2, dim3((K + 255) / 256, (B + bpc - 1) / bpc), dim3(256), 0, s, flat, dmu, dlv, dWmu,
                      dWlv, dbmu, dblv, B, K, Z, bpc);
+  return true;
+}
+
+// dW[k][n] += sum_b z[b,k] dy[b,n] ; db[n] += sum_b dy[b,n]     (decoder Dense, multiscale_vae.py:402-406)
+bool launch_dense_wgrad_dec(const float* z, const float* dy, float* dW, float* db, int B, int Z, int N, hipStream_t s) {
+  if (Z > 32 || N < 256) return false;
+  hipLaunchKernelGGL(k_dense_wgrad_mfma_t, dim3((N + 31) / 32), dim3(256), 0, s, z, dy, dW, db, B, Z, N);
   return true;
 }
 

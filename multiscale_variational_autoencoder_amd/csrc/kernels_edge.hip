@@ -139,19 +139,28 @@ __global__ void __launch_bounds__(256) k_convbase_wgrad_mfma(const float* __rest
     const float* irow = in + ((b * H + (yok ? yy : 0)) * Wd) * CI + ci;
     const float* drow = dy + rr * Wd * 32 + i;
     const float* yrow = y + rr * Wd * 32 + i;
-#pragma unroll 4
-    for (int x = 0; x < Wd; x += 2) {
-      const int xm = x + h;                       // this lane half's pixel
-      const bool mv = xm < Wd;
-      const int xx = xm + e - 1;
-      const float av = (mv && yok && xx >= 0 && xx < Wd) ? irow[xx * CI] : 0.f;
-      float d = 0.f;
-      if (mv) {
-        const float yv = yrow[xm * 32];
-        d = drow[xm * 32] * (yv > 0.f ? 1.0f : yv + 1.0f);
+    for (int x = 0; x < Wd; x += 8) {             // 4 pixel pairs per trip: 12 raw (clamped) loads, then the MFMAs
+      float av[4], dv[4], yv[4], am[4], dm[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int xm = x + 2 * u + h;               // this lane half's pixel
+        const bool mv = xm < Wd;
+        const int xx = xm + e - 1;
+        const bool aok = mv && yok && xx >= 0 && xx < Wd;
+        am[u] = aok ? 1.f : 0.f;
+        dm[u] = mv ? 1.f : 0.f;
+        av[u] = irow[(aok ? xx : 0) * CI];
+        const int xc = mv ? xm : 0;
+        yv[u] = yrow[xc * 32];
+        dv[u] = drow[xc * 32];
       }
-      bsum += d;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, d, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d = dv[u] * (yv[u] > 0.f ? 1.0f : yv[u] + 1.0f) * dm[u];
+        bsum += d;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u] * am[u], d, acc, 0, 0, 0);
+      }
     }
   }
 #pragma unroll

@@ -1169,4 +1169,25 @@ void launch_state_update(float* state, const float* stats, const StateDesc* desc
   hipLaunchKernelGGL(k_state_update, dim3(ndesc), dim3(64), 0, s, state, stats, descs, stat_scale, B);
 }
 
+// g[i] += sum over the n gradient-slot copies (kernels.h: GradSlots); elems and stride are multiples of 4
+__global__ void __launch_bounds__(256) k_slot_sum(float* __restrict__ g, const float* __restrict__ slots, int64_t n4,
+                                                  int64_t stride4, int n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = reinterpret_cast<float4*>(g)[i];
+  const float4* sp = reinterpret_cast<const float4*>(slots) + i;
+#pragma unroll 8
+  for (int k = 0; k < n; ++k) {
+    float4 v = sp[k * stride4];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  reinterpret_cast<float4*>(g)[i] = a;
+}
+
+void launch_slot_sum(float* g, const float* slots, int64_t elems, int64_t stride, int n, hipStream_t s) {
+  ProfScope ps("slot_sum", 4.0 * elems * (n + 2), (double)elems * n, s);
+  const int64_t n4 = elems / 4;
+  hipLaunchKernelGGL(k_slot_sum, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g, slots, n4, stride / 4, n);
+}
+
 }  // namespace mvae

@@ -251,16 +251,21 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_rows(const float* __restrict__
   int64_t m_end = m_begin + rows_per_block;
   if (m_end > M) m_end = M;
 
-  f32x4 px[LX], pg[LG];
+  // Prefetch registers hold RAW loads: every address is clamped to a valid one and the validity mask, the folded
+  // BatchNorm and the squeeze-excite gate are applied when the tile is written to LDS.  With the loads unconditional the
+  // compiler issues them back to back (exec-masked `if (ok) load` bodies each came with their own s_waitcnt vmcnt(0)).
+  f32x4 px[LX], pq[LX], pg[LG];
+  float pm[LX];
+  const f32x4* gate4 = reinterpret_cast<const f32x4*>(pre.gate ? pre.gate : big);   // never null: loads stay uniform
+  const float gate_on = pre.gate ? 1.f : 0.f;
   auto load_tile = [&](int64_t row0) {
-    // decode this lane's first row once, then step RPX rows per load
+    // decode this lane's first row once, then step RPX rows per load (branch-free; the launcher guarantees 2*OW >= RPX)
     int64_t m = row0 + xr;
     int64_t b = m / HWo;
     int rem = (int)(m - b * HWo);
     int oh = rem / g.OW, ow = rem - oh * g.OW;
 #pragma unroll
     for (int j = 0; j < LX; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       bool ok = m < m_end;
       int64_t src = m;
       if (!pointwise) {
@@ -268,21 +273,27 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_rows(const float* __restrict__
         ok = ok && yy >= 0 && yy < g.IH && xx >= 0 && xx < g.IW;
         src = (b * g.IH + yy) * g.IW + xx;
       }
-      if (ok) {
-        v = big4[src * CI4 + xc4];
-        if (pre.scale) v = v * psc + psh;
-        if (pre.gate) v = v * reinterpret_cast<const f32x4*>(pre.gate)[b * CI4 + xc4];
-      }
-      px[j] = v;
+      src = ok ? src : 0;
+      const int64_t bb = ok ? b : 0;
+      px[j] = big4[src * CI4 + xc4];
+      pq[j] = gate4[bb * CI4 + xc4];
+      pm[j] = ok ? 1.f : 0.f;
       m += RPX;
       ow += RPX;
-      while (ow >= g.OW) { ow -= g.OW; if (++oh == g.OH) { oh = 0; ++b; } }
+#pragma unroll
+      for (int wr = 0; wr < 2; ++wr) {
+        const bool c = ow >= g.OW;
+        ow -= c ? g.OW : 0;
+        oh += c ? 1 : 0;
+        const bool c2 = oh >= g.OH;
+        oh = c2 ? 0 : oh;
+        b += c2 ? 1 : 0;
+      }
     }
 #pragma unroll
     for (int j = 0; j < LG; ++j) {
-      int64_t mm = row0 + j * RPG + gr;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      pg[j] = mm < m_end ? small4[mm * CO4 + gc4] : z;
+      const int64_t mm = row0 + j * RPG + gr;
+      pg[j] = small4[(mm < m_end ? mm : m_begin) * CO4 + gc4];
     }
   };
 
@@ -291,9 +302,17 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_rows(const float* __restrict__
   for (; row0 < m_end; row0 += 4 * R) {
     WAVE_LDS_SYNC();       // the previous tile's fragment reads are done
 #pragma unroll
-    for (int j = 0; j < LX; ++j) *reinterpret_cast<f32x4*>(&sX[(j * RPX + xr) * CI + xc4 * 4]) = px[j];
+    for (int j = 0; j < LX; ++j) {
+      f32x4 v = px[j] * psc + psh;                                     // identity when there is no folded BatchNorm
+      const f32x4 q = pq[j] * gate_on + (1.f - gate_on);               // gate, or 1
+      *reinterpret_cast<f32x4*>(&sX[(j * RPX + xr) * CI + xc4 * 4]) = v * q * pm[j];
+    }
 #pragma unroll
-    for (int j = 0; j < LG; ++j) *reinterpret_cast<f32x4*>(&sG[(j * RPG + gr) * CO + gc4 * 4]) = pg[j];
+    for (int j = 0; j < LG; ++j) {
+      const int64_t mm = row0 + j * RPG + gr;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&sG[(j * RPG + gr) * CO + gc4 * 4]) = mm < m_end ? pg[j] : z;
+    }
     WAVE_LDS_SYNC();
     if (row0 + 4 * R < m_end) load_tile(row0 + 4 * R);       // prefetch under the MFMAs
     // all operands of the tile are read from LDS up front (R/2 * (KT+NT) registers): the MFMAs then issue back to
@@ -353,6 +372,206 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_rows(const float* __restrict__
   }
 }
 
+// k x k weight gradient with one block per KERNEL ROW kh: the TG = KW taps of the row share the `small` tile (staged
+// once per 16-row tile, its fragments kept in registers across the taps) and only the gathered `big` tile changes per
+// tap, prefetched one tap ahead.  Against one-tap-per-block (k_wgrad_rows with grid.y = taps) this cuts the L2 -> CU
+// traffic of the 5x5 convolutions from 25 x (big + small) to 25 x big + 5 x small, which is what bounded them.
+template <int CI, int CO, int TG>
+__global__ void __launch_bounds__(256, 2) k_wgrad_taprow(const float* __restrict__ big, const float* __restrict__ small,
+                                                         float* __restrict__ dW, float* __restrict__ db, ConvGeom g,
+                                                         int64_t M, int64_t rows_per_block) {
+  constexpr int KT = CI / 32, NT = CO / 32;
+  constexpr int R = 16;
+  constexpr int CI4 = CI / 4, CO4 = CO / 4;
+  constexpr int LX = R * CI4 / 64, LG = R * CO4 / 64;
+  constexpr int RPX = 64 / CI4, RPG = 64 / CO4;
+  constexpr int TILE = R * (CI + CO);
+  __shared__ __attribute__((aligned(16))) float lds[(4 * TILE > CI * CO) ? 4 * TILE : CI * CO];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* sX = lds + wave * TILE;
+  float* sG = sX + R * CI;
+  const int i = lane & 31, h = lane >> 5;
+  const int kh = blockIdx.y;
+  const int HWo = g.OH * g.OW;
+  const f32x4* big4 = reinterpret_cast<const f32x4*>(big);
+  const f32x4* small4 = reinterpret_cast<const f32x4*>(small);
+  const int xc4 = lane % CI4, xr = lane / CI4, gc4 = lane % CO4, gr = lane / CO4;
+
+  f32x16 acc[TG][KT][NT];
+#pragma unroll
+  for (int t = 0; t < TG; ++t)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][kt][nt][r] = 0.f;
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+
+  const int64_t m_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t m_end = m_begin + rows_per_block;
+  if (m_end > M) m_end = M;
+
+  // raw, clamped prefetch loads; masks applied at the LDS write (see k_wgrad_rows)
+  f32x4 px[LX], pg[LG];
+  float pm[LX];
+  int pb[LX], poh[LX], pow_[LX];                  // decoded (b, oh, ow) of this lane's rows in the current tile
+  auto decode_tile = [&](int64_t row0) {
+    const uint32_t m = (uint32_t)(row0 + xr);     // M < 2^31 (checked by the launcher): 32-bit divisions
+    uint32_t b = m / (uint32_t)HWo;
+    uint32_t rem = m - b * (uint32_t)HWo;
+    int oh = (int)(rem / (uint32_t)g.OW), ow = (int)(rem - (uint32_t)oh * (uint32_t)g.OW);
+    int bi = (int)b;
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+      pb[j] = bi; poh[j] = oh; pow_[j] = ow;
+      ow += RPX;
+#pragma unroll
+      for (int wr = 0; wr < 2; ++wr) {
+        const bool c = ow >= g.OW;
+        ow -= c ? g.OW : 0;
+        oh += c ? 1 : 0;
+        const bool c2 = oh >= g.OH;
+        oh = c2 ? 0 : oh;
+        bi += c2 ? 1 : 0;
+      }
+    }
+  };
+  auto load_big = [&](int64_t row0, int kw) {
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+      const int yy = poh[j] * g.SH + kh - g.PT, xx = pow_[j] * g.SW + kw - g.PL;
+      const bool ok = (row0 + xr + j * RPX < m_end) && yy >= 0 && yy < g.IH && xx >= 0 && xx < g.IW;
+      const int64_t src = ok ? ((int64_t)pb[j] * g.IH + yy) * g.IW + xx : 0;
+      px[j] = big4[src * CI4 + xc4];
+      pm[j] = ok ? 1.f : 0.f;
+    }
+  };
+  auto load_small = [&](int64_t row0) {
+#pragma unroll
+    for (int j = 0; j < LG; ++j) {
+      const int64_t mm = row0 + j * RPG + gr;
+      pg[j] = small4[(mm < m_end ? mm : m_begin) * CO4 + gc4];
+    }
+  };
+
+  int64_t row0 = m_begin + wave * R;
+  if (row0 < m_end) {
+    decode_tile(row0);
+    load_small(row0);
+    load_big(row0, 0);
+  }
+  for (; row0 < m_end; row0 += 4 * R) {
+    WAVE_LDS_SYNC();       // the previous tile's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < LG; ++j) {
+      const int64_t mm = row0 + j * RPG + gr;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&sG[(j * RPG + gr) * CO + gc4 * 4]) = mm < m_end ? pg[j] : z;
+    }
+    float bv[R / 2][NT];
+    const bool more = row0 + 4 * R < m_end;
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      if (t > 0) WAVE_LDS_SYNC();                 // tap t-1's fragments are in registers
+#pragma unroll
+      for (int j = 0; j < LX; ++j) *reinterpret_cast<f32x4*>(&sX[(j * RPX + xr) * CI + xc4 * 4]) = px[j] * pm[j];
+      WAVE_LDS_SYNC();
+      // prefetch: the next tap of this tile, or tap 0 (+ the small tile) of the wave's next tile
+      if (t + 1 < TG) {
+        load_big(row0, t + 1);
+      } else if (more) {
+        decode_tile(row0 + 4 * R);
+        load_small(row0 + 4 * R);
+        load_big(row0 + 4 * R, 0);
+      }
+      if (t == 0) {
+#pragma unroll
+        for (int tt = 0; tt < R / 2; ++tt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            bv[tt][nt] = sG[(h * (R / 2) + tt) * CO + nt * 32 + i];
+            bsum[nt] += bv[tt][nt];
+          }
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {      // fragments in two batches of R/4 row pairs: bounds the registers
+        float av[R / 4][KT];
+#pragma unroll
+        for (int tt = 0; tt < R / 4; ++tt)
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) av[tt][kt] = sX[(h * (R / 2) + half * (R / 4) + tt) * CI + kt * 32 + i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tt = 0; tt < R / 4; ++tt)
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[t][kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt][kt], bv[half * (R / 4) + tt][nt],
+                                                                    acc[t][kt][nt], 0, 0, 0);
+      }
+    }
+  }
+  // ---- per tap: reduce the 4 waves through LDS, then one coalesced float-atomic set per block
+  float* red = lds;
+#pragma unroll
+  for (int t = 0; t < TG; ++t) {
+    for (int wv = 0; wv < 4; ++wv) {
+      __syncthreads();
+      if (wave == wv) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              int ci = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              int idx = ci * CO + nt * 32 + i;
+              red[idx] = (wv == 0 ? 0.f : red[idx]) + acc[t][kt][nt][r];
+            }
+      }
+    }
+    __syncthreads();
+    float* dWt = dW + (int64_t)(kh * g.KW + t) * CI * CO;
+    for (int idx = threadIdx.x; idx < CI * CO; idx += 256) atomicAdd(&dWt[idx], red[idx]);
+  }
+  if (db != nullptr && kh == 0) {
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) red[(wave * 2 + h) * CO + nt * 32 + i] = bsum[nt];
+    __syncthreads();
+    if (threadIdx.x < CO) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[q * CO + threadIdx.x];
+      atomicAdd(&db[threadIdx.x], t);
+    }
+  }
+}
+
+template <int CI, int CO>
+static bool run_wgrad_taprow(const float* big, const float* small, float* dW, float* db, const ConvGeom& g,
+                             hipStream_t s) {
+  if constexpr (CI + CO > 96) {                      // 5 taps x [CI x CO] accumulators must fit the register file
+    return false;
+  } else {
+  const int64_t M = (int64_t)g.B * g.OH * g.OW;
+  if (g.KW != 5 || M >= (1ll << 31)) return false;
+  int64_t chunks = 512 / g.KH;                     // ~512 blocks: two resident 4-wave blocks per CU
+  if (chunks < 1) chunks = 1;
+  int64_t rpb = (M + chunks - 1) / chunks;
+  rpb = (rpb + 63) / 64 * 64;
+  if (rpb < 64) rpb = 64;
+  chunks = (M + rpb - 1) / rpb;
+  hipLaunchKernelGGL((k_wgrad_taprow<CI, CO, 5>), dim3((unsigned)chunks, g.KH), dim3(256), 0, s, big, small, dW, db, g,
+                     M, rpb);
+  return true;
+  }
+}
+
 template <int CI, int CO>
 static void run_wgrad_rows(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, PreOp pre,
                            hipStream_t s) {
@@ -371,9 +590,11 @@ static void run_wgrad_rows(const float* big, const float* small, float* dW, floa
 
 bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, PreOp pre,
                             hipStream_t s) {
+  if (2 * g.OW < 64 / (g.CI / 4)) return false;        // the kernel's branch-free row stepping wraps at most twice
 #define MVAE_WG(A, B_)                                                          \
   if (g.CI == A && g.CO == B_) {                                                \
-    run_wgrad_rows<A, B_>(big, small, dW, db, g, pre, s);                       \
+    if (!(g.KW == 5 && !pre.scale && !pre.gate && run_wgrad_taprow<A, B_>(big, small, dW, db, g, s)))  \
+      run_wgrad_rows<A, B_>(big, small, dW, db, g, pre, s);                     \
     return true;                                                                \
   }
   MVAE_WG(64, 64) MVAE_WG(32, 32) MVAE_WG(64, 32) MVAE_WG(32, 64)
@@ -541,218 +762,188 @@ bool launch_conv_taps_mfma(bool transposed, const float* in, const float* w, con
 //     dot_out[b,c] += sum_{m in image b} Y[m,c] * aux[m,c]          (optional: squeeze-excite gate gradient)
 // which are conv2's pair  (dt2 = dout.W2^T, dW2 = (t1*g)^T dout, dg)  and conv0's pair  (da = dt0.W0^T + dout,
 // dW0 = a^T dt0): 3 tensor passes instead of 5 (the separate kernels re-read both operands).
-// LDS tiles are unpadded and XOR-swizzled per 16-byte chunk (chunk' = chunk ^ (row & (C/4-1))): conflict-free for the
-// row-major float4 staging, the k-permuted ds_read_b128 GEMM fragments and the channel-on-lane wgrad reads alike,
-// and 2 x 32 x C floats per wave keep two 4-wave blocks resident per CU.
+// Both products are MFMA-heavy (AI 32 FLOP/B > the fp32 ridge), so the kernel is built for MFMA occupancy: the block's
+// 4 waves are WR row groups x WN = C/32 column groups; a wave owns 32 rows x 32 output columns of Y and a
+// [C x 32] column slab of dW, which keeps it under 256 registers -> two blocks (8 waves) per CU, one block's
+// staging / epilogue under the other's MFMAs.  LDS tiles are unpadded and XOR-swizzled per 16-byte chunk
+// (chunk' = chunk ^ (row & (C/4-1))): conflict-free for the row-major float4 staging, the k-permuted ds_read_b128
+// GEMM fragments and the channel-on-lane wgrad reads alike.  Y leaves straight from the accumulator layout
+// (each store instruction = two full 128-byte row segments), residual and dot source are read in the same layout.
 // =================================================================================================
 template <int C>
-__global__ void __launch_bounds__(256, 1) k_gemm_dual(const float* __restrict__ X, const float* __restrict__ W,
+__global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ X, const float* __restrict__ W,
                                                       const float* __restrict__ aux, const float* __restrict__ gate,
                                                       const float* __restrict__ residual, float* __restrict__ Y,
                                                       float* __restrict__ dW, float* __restrict__ db,
-                                                      float* __restrict__ dot_out, int64_t M, int64_t rows_per_image) {
-  constexpr int KH = C / 2, NT = C / 32, C4 = C / 4, LD = C / 8, RPL = 64 / C4, MASK = C4 - 1;
-  extern __shared__ __attribute__((aligned(16))) float dl[];
+                                                      float* __restrict__ dot_out, int64_t M, int64_t rows_per_image,
+                                                      int nslots, int64_t slot_stride) {
+  constexpr int KH = C / 2, NT = C / 32, C4 = C / 4, MASK = C4 - 1;
+  constexpr int WN = NT, WR = 4 / WN, TR = 32 * WR;        // block tile = TR rows
+  constexpr int LD = TR * C4 / 256;                        // float4 per thread per tensor (= 4)
+  __shared__ __attribute__((aligned(16))) float sX[TR * C];
+  __shared__ __attribute__((aligned(16))) float sA[TR * C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* sX = dl + wave * 2 * 32 * C;                     // this wave's X tile (later: the Y tile)
-  float* sA = sX + 32 * C;                                // this wave's aux tile
+  const int nw = wave % WN, rw = wave / WN, n0 = nw * 32;
   const int i = lane & 31, h = lane >> 5;
-  float breg[KH][NT];                                     // Wt[k = h*KH + t][n = nt*32 + i], resident in registers
+  float breg[KH];                                          // Wt[k = h*KH + t][n = n0 + i], resident in registers
 #pragma unroll
-  for (int t = 0; t < KH; ++t)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) breg[t][nt] = W[(int64_t)(nt * 32 + i) * C + h * KH + t];
-  const int lc4 = lane % C4, lr = lane / C4;
-  const int64_t ntiles = (M + 127) / 128;
+  for (int t = 0; t < KH; ++t) breg[t] = W[(int64_t)(n0 + i) * C + h * KH + t];
+  const int64_t ntiles = (M + TR - 1) / TR;
   const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
   const f32x4* A4 = reinterpret_cast<const f32x4*>(aux);
-  const f32x4* R4 = reinterpret_cast<const f32x4*>(residual);
-  f32x4* Y4 = reinterpret_cast<f32x4*>(Y);
 #define SWZ4(r, c4) ((r) * C4 + ((c4) ^ ((r) & MASK)))                    /* float4 index */
 #define SWZ1(r, c) ((r) * C + ((((c) >> 2) ^ ((r) & MASK)) << 2) + ((c) & 3)) /* float index */
 
-  f32x16 accw[NT][NT];
+  f32x16 accw[NT];
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accw[kt][nt][r] = 0.f;
-  float bsum[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+    for (int r = 0; r < 16; ++r) accw[kt][r] = 0.f;
+  float bsum = 0.f;
 
   f32x4 stx[LD], sta[LD];
-  auto load_tile = [&](int64_t tile) {
-    const int64_t row0 = tile * 128 + wave * 32;
+  auto load_tile = [&](int64_t tile) {                     // a tile is one contiguous run of TR*C floats
+    const f32x4* px = X4 + tile * (TR * C4) + threadIdx.x;
+    const f32x4* pa = A4 + tile * (TR * C4) + threadIdx.x;
+    const int64_t left = M - tile * TR;
+    const int lim = left < TR ? (int)left : TR;            // valid rows in this tile
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
-      int64_t row = row0 + j * RPL + lr;
+      const bool ok = (j * 256 + (int)threadIdx.x) / C4 < lim;
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      stx[j] = row < M ? X4[row * C4 + lc4] : z;
-      sta[j] = row < M ? A4[row * C4 + lc4] : z;
+      stx[j] = ok ? px[j * 256] : z;
+      sta[j] = ok ? pa[j * 256] : z;
     }
   };
   int64_t tile = blockIdx.x;
   if (tile < ntiles) load_tile(tile);
-  for (; tile < ntiles; tile += gridDim.x) {             // the tile loop is wave-private: no block barrier
-    const int64_t row0 = tile * 128 + wave * 32;
-    WAVE_LDS_SYNC();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * TR + rw * 32;              // this wave's 32 rows
+    __syncthreads();                                       // previous tile fully consumed by all waves
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
-      const int r = j * RPL + lr;
-      reinterpret_cast<f32x4*>(sX)[SWZ4(r, lc4)] = stx[j];
-      reinterpret_cast<f32x4*>(sA)[SWZ4(r, lc4)] = sta[j];
+      const int idx = j * 256 + threadIdx.x;
+      const int r = idx / C4, c4 = idx % C4;
+      reinterpret_cast<f32x4*>(sX)[SWZ4(r, c4)] = stx[j];
+      reinterpret_cast<f32x4*>(sA)[SWZ4(r, c4)] = sta[j];
     }
-    WAVE_LDS_SYNC();
+    __syncthreads();
     if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);          // prefetch under the MFMAs
-    // ---- Y tile = X . Wt
-    f32x16 acc[NT];
+    // ---- Y tile = X . Wt   (32 rows x 32 columns per wave)
+    f32x16 acc;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+      f32x4 afr[KH / 4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-    f32x4 afr[KH / 4];
+      for (int q = 0; q < KH / 4; ++q)
+        afr[q] = reinterpret_cast<const f32x4*>(sX)[SWZ4(rw * 32 + i, h * (C4 / 2) + q)];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < KH / 4; ++q) afr[q] = reinterpret_cast<const f32x4*>(sX)[SWZ4(i, h * (C4 / 2) + q)];
-    __builtin_amdgcn_sched_barrier(0);
+      for (int q = 0; q < KH / 4; ++q)
 #pragma unroll
-    for (int q = 0; q < KH / 4; ++q)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[q * 4 + e][nt], acc[nt], 0, 0, 0);
-    // the residual tile is fetched here, a whole MFMA phase ahead of its use (1 wave / SIMD: 512 registers)
-    f32x4 res[LD];
-    if (residual) {
-#pragma unroll
-      for (int j = 0; j < LD; ++j) {
-        int64_t row = row0 + j * RPL + lr;
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        res[j] = row < M ? R4[row * C4 + lc4] : z;
-      }
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[q * 4 + e], acc, 0, 0, 0);
     }
-    // ---- dW += (aux * gate)^T X over the 32 rows of the tile (lane half h: rows 16h .. 16h+15)
+    // the residual is fetched in the accumulator layout, a whole MFMA phase ahead of its use
+    const int64_t left = M - row0 - 4 * h;
+    const int lim = left < 32 ? (int)left : 32;            // row (r&3)+8(r>>2) of this lane half is valid below lim
+    const int64_t ebase = (row0 + 4 * h) * C + n0 + i;
+    float res[16];
+    if (residual) {
+      const float* pr = residual + ebase;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) res[r] = ((r & 3) + 8 * (r >> 2)) < lim ? pr[((r & 3) + 8 * (r >> 2)) * C] : 0.f;
+    }
+    // ---- dW[:, n0..n0+31] += (aux * gate)^T X over the wave's 32 rows (lane half h: rows 16h .. 16h+15)
     float gl[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
       gl[kt] = (gate && row0 < M) ? gate[(row0 / rows_per_image) * C + kt * 32 + i] : 1.0f;
-    // operands in two batches of 8 row-pairs, each read from LDS before its MFMAs are issued
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      float av[8][NT], bv[8][NT];
+      float av[8][NT], bv[8];
 #pragma unroll
       for (int tt = 0; tt < 8; ++tt) {
-        const int r = h * 16 + half * 8 + tt;
+        const int r = rw * 32 + h * 16 + half * 8 + tt;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) av[tt][kt] = sA[SWZ1(r, kt * 32 + i)] * gl[kt];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[tt][nt] = sX[SWZ1(r, nt * 32 + i)];
+        bv[tt] = sX[SWZ1(r, n0 + i)];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tt = 0; tt < 8; ++tt) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bsum[nt] += bv[tt][nt];
+        bsum += bv[tt];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            accw[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt][kt], bv[tt][nt], accw[kt][nt], 0, 0, 0);
+          accw[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tt][kt], bv[tt], accw[kt], 0, 0, 0);
       }
     }
-    WAVE_LDS_SYNC();     // X tile fully consumed: it becomes the Y tile
+    // ---- epilogue straight from the accumulator layout
+    float dsum = 0.f;
+    float* py = Y + ebase;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-        sX[SWZ1(rr, nt * 32 + i)] = acc[nt][r];
-      }
-    WAVE_LDS_SYNC();
-    f32x4 dsum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < LD; ++j) {
-      const int r = j * RPL + lr;
-      int64_t row = row0 + r;
-      f32x4 v = reinterpret_cast<const f32x4*>(sX)[SWZ4(r, lc4)];
-      if (residual) v = v + res[j];
-      if (row < M) {
-        Y4[row * C4 + lc4] = v;
-        if (dot_out) dsum += v * reinterpret_cast<const f32x4*>(sA)[SWZ4(r, lc4)];
+    for (int r = 0; r < 16; ++r) {
+      const int rc = (r & 3) + 8 * (r >> 2);
+      float v = acc[r];
+      if (residual) v += res[r];
+      if (rc < lim) {
+        py[rc * C] = v;
+        if (dot_out) dsum += v * sA[SWZ1(rw * 32 + rc + 4 * h, n0 + i)];
       }
     }
     if (dot_out) {
-#pragma unroll
-      for (int off = C4; off < 64; off <<= 1)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dsum[e] += __shfl_xor(dsum[e], off, 64);
-      if (lane < C4 && row0 < M) {
-        float* dst = dot_out + (row0 / rows_per_image) * C + lc4 * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(dst + e, dsum[e]);
-      }
+      dsum += __shfl_xor(dsum, 32, 64);
+      if (h == 0 && row0 < M) atomicAdd(dot_out + (row0 / rows_per_image) * C + n0 + i, dsum);
     }
   }
-#undef SWZ4
-#undef SWZ1
-  // ---- reduce the 4 waves' dW tiles through LDS, then one coalesced float-atomic set per block
-  __syncthreads();
-  float* red = dl;
-  for (int wv = 0; wv < 4; ++wv) {
-    if (wave == wv) {
+  // ---- reduce the row groups' dW slabs through LDS, then one coalesced float-atomic set per block
+  float* red = sX;                                         // C*C floats <= TR*C
+  for (int step = 0; step < WR; ++step) {
+    __syncthreads();
+    if (rw == step) {
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            int ci = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            int idx = ci * C + nt * 32 + i;
-            red[idx] = (wv == 0 ? 0.f : red[idx]) + accw[kt][nt][r];
-          }
-    }
-    __syncthreads();
-  }
-  for (int idx = threadIdx.x; idx < C * C; idx += 256) atomicAdd(&dW[idx], red[idx]);
-  if (db != nullptr) {
-    __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) red[(wave * 2 + h) * C + nt * 32 + i] = bsum[nt];
-    __syncthreads();
-    if (threadIdx.x < C) {
-      float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) t += red[q * C + threadIdx.x];
-      atomicAdd(&db[threadIdx.x], t);
+        for (int r = 0; r < 16; ++r) {
+          const int ci = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int idx = ci * C + n0 + i;
+          red[idx] = (step == 0 ? 0.f : red[idx]) + accw[kt][r];
+        }
     }
   }
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (h == 0) sA[rw * C + n0 + i] = bsum;
+  __syncthreads();
+  const int64_t slot = (int64_t)(blockIdx.x % nslots) * slot_stride;
+  for (int idx = threadIdx.x; idx < C * C; idx += 256) atomicAdd(&dW[slot + idx], red[idx]);
+  if (db != nullptr && threadIdx.x < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < WR; ++q) t += sA[q * C + threadIdx.x];
+    atomicAdd(&db[slot + threadIdx.x], t);
+  }
+#undef SWZ4
+#undef SWZ1
 }
 
 template <int C>
 static void run_gemm_dual(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
-                          float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rpi, hipStream_t s) {
-  const size_t lds = (size_t)(4 * 2 * 32 * C) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dual<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
-  int64_t ntiles = (M + 127) / 128;
-  int grid = (int)(ntiles < 512 ? ntiles : 512);          // 256 CUs x (up to) 2 resident blocks
-  hipLaunchKernelGGL((k_gemm_dual<C>), dim3(grid), dim3(256), lds, s, X, W, aux, gate, residual, Y, dW, db, dot_out, M,
-                     rpi);
+                          float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rpi, GradSlots sl,
+                          hipStream_t s) {
+  constexpr int TR = 32 * (4 / (C / 32));
+  int64_t ntiles = (M + TR - 1) / TR;
+  int grid = (int)(ntiles < 512 ? ntiles : 512);          // 256 CUs x 2 resident blocks
+  hipLaunchKernelGGL((k_gemm_dual<C>), dim3(grid), dim3(256), 0, s, X, W, aux, gate, residual, Y, sl.at(dW), sl.at(db),
+                     dot_out, M, rpi, sl.count(), sl.stride);
 }
 
 // conv (1x1, C -> C) backward pair in one pass; false = shape not covered
 bool launch_gemm_dual_mfma(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
                            float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
-                           hipStream_t s) {
+                           GradSlots sl, hipStream_t s) {
   if ((gate || dot_out) && (rows_per_image % 32) != 0) return false;
-  if (C == 64) { run_gemm_dual<64>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, s); return true; }
-  if (C == 32) { run_gemm_dual<32>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, s); return true; }
+  if (C == 64) { run_gemm_dual<64>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, sl, s); return true; }
+  if (C == 32) { run_gemm_dual<32>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, sl, s); return true; }
   return false;
 }
 

@@ -3,6 +3,8 @@
 // kernel's average duration and algorithmic bytes/flops for the roofline line.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -12,8 +14,10 @@ struct ProfRec { int tag; hipEvent_t a, b; double bytes, flops; };
 
 struct Profiler {
   bool on = false;
+  bool by_size = getenv("MVAE_PROF_SIZES") != nullptr;   // diagnostics: split every tag by log2(bytes)
   std::vector<std::string> tags;
   std::vector<ProfRec> recs;
+  std::vector<hipStream_t> streams;           // by_size mode: launch streams in order of first appearance
   int tag_id(const char* name) {
     for (size_t i = 0; i < tags.size(); ++i)
       if (tags[i] == name) return (int)i;
@@ -30,7 +34,19 @@ struct ProfScope {
     Profiler& p = profiler();
     if (!p.on) return;
     ProfRec r;
-    r.tag = p.tag_id(tag); r.bytes = bytes; r.flops = flops;
+    if (p.by_size) {
+      char buf[96];
+      int lg = 0;
+      while ((1ll << lg) < (long long)bytes) ++lg;
+      size_t si = 0;
+      while (si < p.streams.size() && p.streams[si] != stream) ++si;
+      if (si == p.streams.size()) p.streams.push_back(stream);
+      snprintf(buf, sizeof(buf), "%s#%dB/q%d", tag, lg, (int)si);
+      r.tag = p.tag_id(buf);
+    } else {
+      r.tag = p.tag_id(tag);
+    }
+    r.bytes = bytes; r.flops = flops;
     (void)hipEventCreate(&r.a);
     (void)hipEventCreate(&r.b);
     (void)hipEventRecord(r.a, s);

@@ -26,6 +26,7 @@ constexpr int kConvBaseFilters = 32;      // multiscale_vae.py:50
 constexpr float kDropout = 0.1f;          // multiscale_vae.py:58
 constexpr float kSeBnMomentum = 0.99f, kSeBnEps = 1e-3f;     // keras BatchNormalization defaults (layer_blocks.py:448)
 constexpr float kDecBnMomentum = 0.999f, kDecBnEps = 1e-4f;  // multiscale_vae.py:420-421
+constexpr int kGradSlots = 16;
 constexpr int64_t kAlign = 64;            // floats; every tensor / buffer starts on a 256-byte line
 constexpr int kChunk = 8192;
 
@@ -89,7 +90,8 @@ struct mvae_handle {
   std::vector<ChunkDesc> chunks;
   std::vector<StateDesc> sdescs;
   // workspace offsets of the fixed tables / buffers
-  int64_t off_chunks = 0, off_sdescs = 0, off_norms = 0;
+  int64_t off_chunks = 0, off_sdescs = 0, off_norms = 0, off_slots = 0;
+  GradSlots gslots;                         // kernels.h: spread small-gradient atomics over kGradSlots arena copies
   // bound memory
   bool bound = false;
   int device = -1;
@@ -346,6 +348,7 @@ int build_plan(mvae_handle* h) {
   h->off_sdescs = b.ws_alloc((int64_t)(h->sdescs.size() * sizeof(StateDesc) + 3) / 4);
   h->off_norms = b.ws_alloc((int64_t)h->params.size());
   h->off_seed = b.ws_alloc(kAlign);
+  h->off_slots = b.ws_alloc((int64_t)kGradSlots * h->P);
   h->ws_floats = b.wcur;
   return MVAE_OK;
 }
@@ -379,6 +382,9 @@ void rebase_all(mvae_handle* h) {
   h->d_chunks = reinterpret_cast<ChunkDesc*>(base + h->off_chunks);
   h->d_sdescs = reinterpret_cast<StateDesc*>(base + h->off_sdescs);
   h->d_norms = base + h->off_norms;
+  h->gslots.base = base + h->off_slots;
+  h->gslots.stride = h->P;
+  h->gslots.n = kGradSlots;
 }
 
 // ---- scratch pool (per scale, static order => stable pointers under graph capture) ----------
@@ -482,7 +488,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
     launch_zero(sc.dg, (int64_t)B * c, s);
     // dt2 = dout . W2^T ; dW2 += (t1*g)^T dout ; db2 ; dg = sum_hw dt2 * t1     -- one pass over (dout, t1)
     dual2 = launch_gemm_dual_mfma(dout, P + m.w2, m.t1, m.g, nullptr, bufB, G + m.w2, G + m.b2, sc.dg, (int64_t)B * HW, HW,
-                                  c, s);
+                                  c, h->gslots, s);
   }
   if (!dual2) {
     {
@@ -523,7 +529,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
     ProfScope ps(c == 64 ? "k_gemm_dual<64>" : "k_gemm_dual<32>", 16.0 * B * HW * c, 4.0 * B * HW * c * c, s);
     // da = dt0pre . W0^T + dout ; dW0 += a^T dt0pre ; db0     -- one pass over (dt0pre, a, dout)
     dual0 = launch_gemm_dual_mfma(bufC, P + m.w0, x, nullptr, dout, bufB, G + m.w0, G + m.b0, nullptr, (int64_t)B * HW, HW,
-                                  c, s);
+                                  c, h->gslots, s);
   }
   if (!dual0) {
     {
@@ -748,6 +754,8 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   h->device = device;
   h->dp = params; h->dr = reduce_arena; h->da = accum; h->ds = state; h->ws = static_cast<float*>(workspace);
   rebase_all(h);
+  h->gslots.gbase = h->dr;
+  if (const char* v = getenv("MVAE_GRAD_SLOTS")) h->gslots.n = atoi(v) > 0 && atoi(v) <= kGradSlots ? atoi(v) : 0;
   e = hipMemcpy(h->d_chunks, h->chunks.data(), h->chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
   if (e == hipSuccess && !h->sdescs.empty())
     e = hipMemcpy(h->d_sdescs, h->sdescs.data(), h->sdescs.size() * sizeof(StateDesc), hipMemcpyHostToDevice);
@@ -906,6 +914,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
   PreOp none{nullptr, nullptr, nullptr};
   h->ev_next = 0;
   launch_zero(G, (int64_t)(h->P), s);
+  if (h->gslots.n) launch_zero(h->gslots.base, (int64_t)h->gslots.n * h->P, s);
   // ---- loss -> clip/denormalise -> merge
   launch_loss_bwd(h->last_x, h->recon, h->scales[0].merged, h->sgn, h->scales[0].dy, B, c.input_h, c.input_w, C,
                   c.min_value, c.max_value, r_factor / (float)B, s);
@@ -963,7 +972,13 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     // ---- decoder Dense, sampling + KL, encoder Dense heads
     {
       hipStream_t w = wgrad_begin(h, sc, s);
-      launch_gemm_tn(sc.zs, d, G + sc.dd_w, G + sc.dd_b, B, sc.z, (int)sc.K, nullptr, nullptr, nullptr, w);
+      bool fused_ddw;
+      {
+        ProfScope ps("dense_wgrad_dec", 4.0 * (B * (double)sc.K + sc.K * sc.z), 2.0 * B * sc.K * sc.z, w);
+        fused_ddw = launch_dense_wgrad_dec(sc.zs, d, G + sc.dd_w, G + sc.dd_b, B, sc.z, (int)sc.K, w);
+      }
+      if (!fused_ddw)
+        launch_gemm_tn(sc.zs, d, G + sc.dd_w, G + sc.dd_b, B, sc.z, (int)sc.K, nullptr, nullptr, nullptr, w);
       wgrad_reads(h, sc, d, w);
     }
     bool fused_dz;
@@ -1036,6 +1051,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     release(sc, d);
   }
   join_scales(h, s_main);
+  if (h->gslots.n) launch_slot_sum(G, h->gslots.base, h->P, h->gslots.stride, h->gslots.n, s_main);
   };
   int rc = MVAE_OK;
   if (h->last_x == h->xin && h->last_eps == h->eps_buf)
