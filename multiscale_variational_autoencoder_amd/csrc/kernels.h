@@ -83,6 +83,11 @@ void launch_spatial_sum(const float* x, float* out, int B, int64_t HW, int C, fl
 void launch_spatial_dot(const float* a, const float* b, float* out, int B, int64_t HW, int C, hipStream_t s);
 // out[c] += sum_m x[m,c]
 void launch_colsum(const float* x, float* out, int64_t M, int C, hipStream_t s);
+// vectorised column statistics into slot copies (kernels_opt.hip); mode 0: sum, mode 1: squared deviations from
+// mean = inv_m * (sum of the msl slot copies of msum).  false = shape not covered.
+bool launch_colstat_opt(int mode, const float* x, const float* msum, int msl, float inv_m, float* out, int nslots,
+                        int64_t slot_stride, int64_t M, int C, hipStream_t s);
+constexpr int kStatSlots = 16;
 // out[c] += sum_m (x[m,c]-mean[c])^2
 void launch_colsqdev(const float* x, const float* mean, float* out, int64_t M, int C, hipStream_t s);
 // out0[c] += sum_m d ; out1[c] += sum_m d * (x-mean)*invstd
@@ -115,7 +120,7 @@ void launch_bn1d_bwd(const float* dy, const float* xhat, const float* invstd, co
 // training: mean = sum/M, var=sqdev/M -> scale/shift, stats out; inference: from moving stats
 void launch_bn2d_finalize(const float* sum, const float* sqdev, const float* gamma, const float* beta,
                           const float* mov_mean, const float* mov_var, float* mean, float* invstd, float* scale,
-                          float* shift, float* stat_mean, float* stat_var, int64_t M, int C, float eps, int training,
+                          float* shift, float* stat_mean, float* stat_var, int64_t M, int C, float eps, int training, int nslots,
                           hipStream_t s);
 void launch_scale_vec(float* v, float a, int n, hipStream_t s);
 // dx = scale_c * (d - sum_d/M - xhat * sum_dx/M)   in place on d ; dgamma += sum_dx ; dbeta += sum_d
@@ -175,9 +180,11 @@ bool launch_convbase_wgrad(const float* in, const float* dy, const float* y, flo
                            int CI, int CO, hipStream_t s);
 bool launch_head_fwd(const float* x, const float* scale, const float* shift, const float* W, const float* bias,
                      float* y, int64_t M, int dc, int C, hipStream_t s);
+int head_slots();
+// S: [head_slots()][2][dc] floats, zeroed by the caller; adds dW, db (gradient slots), dgamma, dbeta
 bool launch_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,
-                     const float* shift, const float* mean, const float* invstd, float* S1, float* S2, float* dW,
-                     float* db, float* dout, int64_t M, int dc, int C, hipStream_t s);
+                     const float* shift, const float* mean, const float* invstd, float* S, float* dW, float* db,
+                     float* dgamma, float* dbeta, float* dout, int64_t M, int dc, int C, GradSlots sl, hipStream_t s);
 // sliding-row depthwise kernels (kernels_dw.hip); false = shape not covered
 bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* out, float* gap, int B, int H, int W,
                        int C, hipStream_t s);

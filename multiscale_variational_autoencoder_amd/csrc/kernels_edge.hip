@@ -110,10 +110,71 @@ __global__ void __launch_bounds__(256) k_convbase_wgrad(const float* __restrict_
   }
 }
 
+typedef float f32x16e __attribute__((ext_vector_type(16)));
+// MFMA form of the conv_base forward for 9*CI <= 32: out[32 pixels][32 co] = patch[32 pixels][9*CI] . W[9*CI][32],
+// two patch elements per v_mfma_f32_32x32x2_f32 (lane half h takes element 2s + h).  A wave owns 32 consecutive
+// pixels; W (one column per lane) stays in registers; the patch loads are raw + clamped, issued ahead of the MFMAs;
+// D leaves straight from the accumulator layout (each store instruction = two whole 128-byte pixels) after bias + ELU.
+template <int CI>
+__global__ void __launch_bounds__(256) k_convbase_fwd_mfma(const float* __restrict__ in, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int B, int H, int Wd, int ntiles) {
+  constexpr int KP = 9 * CI, NS = (KP + 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  float wreg[NS];
+  int dy_[NS], dx_[NS], dc_[NS];
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    const int k = 2 * st + h;
+    const bool kv = k < KP;
+    const int tap = kv ? k / CI : 0;
+    dy_[st] = kv ? tap / 3 - 1 : -100000;                 // an invalid k never passes the bounds test
+    dx_[st] = tap % 3 - 1;
+    dc_[st] = kv ? k % CI : 0;
+    wreg[st] = kv ? W[k * 32 + i] : 0.f;
+  }
+  const float bz = bias[i];
+  const uint32_t M = (uint32_t)B * H * Wd;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const uint32_t p = (uint32_t)tile * 32 + i;
+    const bool pv = p < M;
+    const uint32_t pc = pv ? p : 0;
+    const uint32_t q = pc / (uint32_t)Wd;
+    const int x = (int)(pc - q * (uint32_t)Wd);
+    const uint32_t b = q / (uint32_t)H;
+    const int y = (int)(q - b * (uint32_t)H);
+    float av[NS], am[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const int yy = y + dy_[st], xx = x + dx_[st];
+      const bool ok = pv && yy >= 0 && yy < H && xx >= 0 && xx < Wd;
+      const int64_t src = ok ? (((int64_t)b * H + yy) * Wd + xx) * CI + dc_[st] : 0;
+      av[st] = in[src];
+      am[st] = ok ? 1.f : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16e acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st] * am[st], wreg[st], acc, 0, 0, 0);
+    const int64_t left = (int64_t)M - (int64_t)tile * 32 - 4 * h;
+    const int lim = left < 32 ? (int)left : 32;
+    float* po = out + ((int64_t)tile * 32 + 4 * h) * 32 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rc = (r & 3) + 8 * (r >> 2);
+      float v = acc[r] + bz;
+      v = v > 0.f ? v : expm1f(v);
+      if (rc < lim) po[rc * 32] = v;
+    }
+  }
+}
+
 // MFMA form of the conv_base weight gradient for 9*CI <= 32 (C <= 3): the [27 x 32] gradient is ONE 32x32 tile,
 // D[i = patch element k][j = co] += patch[m][k] * dpre[m][co], two pixels m per v_mfma_f32_32x32x2_f32.
 // A wave walks whole image rows; lane i decodes its patch element (a, e, ci) once.  4 waves reduce through LDS.
-typedef float f32x16e __attribute__((ext_vector_type(16)));
 __global__ void __launch_bounds__(256) k_convbase_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ dy,
                                                              const float* __restrict__ y, float* __restrict__ dW,
                                                              float* __restrict__ db, int B, int H, int Wd, int CI,
@@ -213,118 +274,150 @@ __global__ void __launch_bounds__(256) k_head_fwd(const f32x4* __restrict__ x, c
 
 // backward pass 1 (reduction): with dxbn[m,c] = sum_o dy[m,o] W[c][o], xhat = (x - mean) * invstd,
 //   S1[c] += dxbn ; S2[c] += dxbn * xhat ; dW[c][o] += (x*scale+shift) * dy[m,o] ; db[o] += dy[m,o]
+// C (output channels) is a template parameter so every per-output loop is straight-line code; pixels are taken four at
+// a time with raw clamped loads ahead of the arithmetic.  The per-thread partial sums are folded over the pixel lanes
+// with wave shuffles, over the 4 waves through LDS, and leave as ONE atomic set per block into slot (block % nslots):
+// S = [nslots][2][dc] (summed by the apply pass), dW/db through the gradient slots (kernels.h: GradSlots).
+constexpr int kHeadSlots = 16;
+template <int C>
 __global__ void __launch_bounds__(256) k_head_bwd_reduce(const f32x4* __restrict__ x, const float* __restrict__ dy,
                                                          const float* __restrict__ W, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, float* __restrict__ S1,
-                                                         float* __restrict__ S2, float* __restrict__ dW,
-                                                         float* __restrict__ db, int64_t M, int dc4, int C, int64_t ppb) {
-  __shared__ float red[48 * 256];
+                                                         const float* __restrict__ invstd, float* __restrict__ S,
+                                                         float* __restrict__ dW, float* __restrict__ db, int64_t M,
+                                                         int dc4, int64_t ppb, int nslots, int64_t slot_stride) {
+  constexpr int NQ = 8 + 5 * C;                       // s1[4] s2[4] gw[4][C] gb[C]
+  __shared__ float red[4][NQ][64];
   const int c4 = threadIdx.x % dc4, pl = threadIdx.x / dc4, npl = 256 / dc4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4], sh = reinterpret_cast<const f32x4*>(shift)[c4];
   const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
-  float w[4][8];
+  float w[4][C];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int o = 0; o < 8; ++o) w[e][o] = o < C ? W[(c4 * 4 + e) * C + o] : 0.f;
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, gw[4][8], gb[8];
+    for (int o = 0; o < C; ++o) w[e][o] = W[(c4 * 4 + e) * C + o];
+  float q[NQ];
 #pragma unroll
-  for (int o = 0; o < 8; ++o) {
-    gb[o] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) gw[e][o] = 0.f;
-  }
+  for (int k = 0; k < NQ; ++k) q[k] = 0.f;
   const int64_t p0 = (int64_t)blockIdx.x * ppb;
   int64_t p1 = p0 + ppb;
   if (p1 > M) p1 = M;
-  for (int64_t p = p0 + pl; p < p1; p += npl) {
-    const f32x4 xv = x[p * dc4 + c4];
-    float d[8];
+  for (int64_t pb = p0 + pl; pb < p1; pb += 4 * npl) {
+    f32x4 xv[4];
+    float d[4][C], msk[4];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) d[o] = o < C ? dy[p * C + o] : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const int64_t p = pb + u * npl;
+      const bool ok = p < p1;
+      const int64_t pc = ok ? p : p0;
+      msk[u] = ok ? 1.f : 0.f;
+      xv[u] = x[pc * dc4 + c4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float dx = 0.f;
-#pragma unroll
-      for (int o = 0; o < 8; ++o) dx += d[o] * w[e][o];
-      const float xh = (xv[e] - mu[e]) * is[e], xb = xv[e] * sc[e] + sh[e];
-      s1[e] += dx;
-      s2[e] += dx * xh;
-#pragma unroll
-      for (int o = 0; o < 8; ++o) gw[e][o] += xb * d[o];
+      for (int o = 0; o < C; ++o) d[u][o] = dy[pc * C + o];
     }
-    if (c4 == 0) {
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int o = 0; o < 8; ++o) gb[o] += d[o];
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int o = 0; o < C; ++o) d[u][o] *= msk[u];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float dx = 0.f;
+#pragma unroll
+        for (int o = 0; o < C; ++o) dx += d[u][o] * w[e][o];
+        const float xh = (xv[u][e] - mu[e]) * is[e], xb = xv[u][e] * sc[e] + sh[e];
+        q[e] += dx;
+        q[4 + e] += dx * xh;
+#pragma unroll
+        for (int o = 0; o < C; ++o) q[8 + e * C + o] += xb * d[u][o];
+      }
+#pragma unroll
+      for (int o = 0; o < C; ++o) q[8 + 4 * C + o] += d[u][o];
     }
   }
-  // block reduction over the pixel lanes through LDS; quantity q: s1 0..3, s2 4..7, gw 8 + 8e + o, gb 40 + o
+  // fold the pixel lanes of the wave (lanes with equal lane % dc4), then the 4 waves through LDS
+  for (int off = dc4; off < 64; off <<= 1) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    red[e * 256 + threadIdx.x] = s1[e];
-    red[(4 + e) * 256 + threadIdx.x] = s2[e];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) red[(8 + e * 8 + o) * 256 + threadIdx.x] = gw[e][o];
+    for (int k = 0; k < NQ; ++k) q[k] += __shfl_xor(q[k], off, 64);
   }
 #pragma unroll
-  for (int o = 0; o < 8; ++o) red[(40 + o) * 256 + threadIdx.x] = gb[o];
+  for (int k = 0; k < NQ; ++k) red[wave][k][lane] = q[k];
   __syncthreads();
-  if (pl == 0) {
-    auto total = [&](int q) {
-      float t = 0.f;
-      for (int r = 0; r < npl; ++r) t += red[q * 256 + r * dc4 + c4];
-      return t;
-    };
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      atomicAdd(&S1[c4 * 4 + e], total(e));
-      atomicAdd(&S2[c4 * 4 + e], total(4 + e));
-#pragma unroll
-      for (int o = 0; o < 8; ++o)
-        if (o < C) atomicAdd(&dW[(c4 * 4 + e) * C + o], total(8 + e * 8 + o));
-    }
-    if (c4 == 0) {
-#pragma unroll
-      for (int o = 0; o < 8; ++o)
-        if (o < C) atomicAdd(&db[o], total(40 + o));
-    }
+  float* Ss = S + (int64_t)(blockIdx.x % kHeadSlots) * 2 * dc4 * 4;
+  const int64_t gslot = (int64_t)(blockIdx.x % nslots) * slot_stride;
+  float* dWs = dW + gslot;
+  float* dbs = db + gslot;
+  for (int u = threadIdx.x; u < NQ * dc4; u += 256) {
+    const int k = u / dc4, cc = u % dc4;
+    if (k >= 8 + 4 * C && cc != 0) continue;          // db: once per pixel, take channel group 0's copy
+    const float t = red[0][k][cc] + red[1][k][cc] + red[2][k][cc] + red[3][k][cc];
+    if (k < 4) atomicAdd(&Ss[cc * 4 + k], t);
+    else if (k < 8) atomicAdd(&Ss[dc4 * 4 + cc * 4 + (k - 4)], t);
+    else if (k < 8 + 4 * C) atomicAdd(&dWs[(cc * 4 + (k - 8) / C) * C + (k - 8) % C], t);
+    else atomicAdd(&dbs[k - 8 - 4 * C], t);
   }
 }
 
-// backward pass 2 (apply): d[m,c] = gamma*invstd * (dxbn - S1/M - xhat * S2/M)
+// backward pass 2 (apply): d[m,c] = gamma*invstd * (dxbn - S1/M - xhat * S2/M); block 0 also adds the BatchNorm
+// parameter gradients dgamma += S2, dbeta += S1
+template <int C>
 __global__ void __launch_bounds__(256) k_head_bwd_apply(const f32x4* __restrict__ x, const float* __restrict__ dy,
                                                         const float* __restrict__ W, const float* __restrict__ gamma,
                                                         const float* __restrict__ mean,
-                                                        const float* __restrict__ invstd, const float* __restrict__ S1,
-                                                        const float* __restrict__ S2, f32x4* __restrict__ dout,
-                                                        int64_t M, int dc4, int C) {
+                                                        const float* __restrict__ invstd, const float* __restrict__ S,
+                                                        f32x4* __restrict__ dout, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int64_t M, int dc4, int nslots) {
   const int c4 = threadIdx.x % dc4, pl = threadIdx.x / dc4, ppb = 256 / dc4;
   const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
   const f32x4 gm = reinterpret_cast<const f32x4*>(gamma)[c4];
   const float inv_m = 1.0f / (float)M;
-  const f32x4 m1 = reinterpret_cast<const f32x4*>(S1)[c4] * inv_m, m2 = reinterpret_cast<const f32x4*>(S2)[c4] * inv_m;
-  float w[4][8];
+  f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < nslots; ++k) {
+    t1 += reinterpret_cast<const f32x4*>(S + (int64_t)k * 2 * dc4 * 4)[c4];
+    t2 += reinterpret_cast<const f32x4*>(S + (int64_t)k * 2 * dc4 * 4 + dc4 * 4)[c4];
+  }
+  if (blockIdx.x == 0 && pl == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dgamma[c4 * 4 + e] += t2[e];
+      dbeta[c4 * 4 + e] += t1[e];
+    }
+  }
+  const f32x4 m1 = t1 * inv_m, m2 = t2 * inv_m;
+  float w[4][C];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int o = 0; o < 8; ++o) w[e][o] = o < C ? W[(c4 * 4 + e) * C + o] : 0.f;
-  for (int64_t p = (int64_t)blockIdx.x * ppb + pl; p < M; p += (int64_t)gridDim.x * ppb) {
-    const f32x4 xv = x[p * dc4 + c4];
-    float d[8];
+    for (int o = 0; o < C; ++o) w[e][o] = W[(c4 * 4 + e) * C + o];
+  const int64_t stride = (int64_t)gridDim.x * ppb;
+  for (int64_t pb = (int64_t)blockIdx.x * ppb + pl; pb < M; pb += 4 * stride) {
+    f32x4 xv[4];
+    float d[4][C];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) d[o] = o < C ? dy[p * C + o] : 0.f;
-    f32x4 r;
+    for (int u = 0; u < 4; ++u) {
+      const int64_t p = pb + u * stride;
+      const int64_t pc = p < M ? p : pb;
+      xv[u] = x[pc * dc4 + c4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float dx = 0.f;
-#pragma unroll
-      for (int o = 0; o < 8; ++o) dx += d[o] * w[e][o];
-      const float xh = (xv[e] - mu[e]) * is[e];
-      r[e] = gm[e] * is[e] * (dx - m1[e] - xh * m2[e]);
+      for (int o = 0; o < C; ++o) d[u][o] = dy[pc * C + o];
     }
-    dout[p * dc4 + c4] = r;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float dx = 0.f;
+#pragma unroll
+        for (int o = 0; o < C; ++o) dx += d[u][o] * w[e][o];
+        const float xh = (xv[u][e] - mu[e]) * is[e];
+        r[e] = gm[e] * is[e] * (dx - m1[e] - xh * m2[e]);
+      }
+      const int64_t p = pb + u * stride;
+      if (p < M) dout[p * dc4 + c4] = r;
+    }
   }
 }
 
@@ -335,6 +428,13 @@ bool launch_convbase_fwd(const float* in, const float* W, const float* bias, flo
                          int CO, hipStream_t s) {
   if (CO != 32 || CI > 4) return false;
   int64_t M = (int64_t)B * H * Wd;
+  if (M < (1ll << 31) - 64 && (CI == 3 || CI == 1)) {
+    const int ntiles = (int)((M + 31) / 32);
+    const int grid = cap_grid((ntiles + 3) / 4);
+    if (CI == 3) hipLaunchKernelGGL(k_convbase_fwd_mfma<3>, dim3(grid), dim3(256), 0, s, in, W, bias, out, B, H, Wd, ntiles);
+    else hipLaunchKernelGGL(k_convbase_fwd_mfma<1>, dim3(grid), dim3(256), 0, s, in, W, bias, out, B, H, Wd, ntiles);
+    return true;
+  }
   hipLaunchKernelGGL(k_convbase_fwd, dim3(cap_grid((M + 31) / 32)), dim3(256), 0, s, in, W, bias, out, B, H, Wd, CI);
   return true;
 }
@@ -369,17 +469,29 @@ bool launch_head_fwd(const float* x, const float* scale, const float* shift, con
                      bias, y, M, dc4, C);
   return true;
 }
-bool launch_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,
-                     const float* shift, const float* mean, const float* invstd, float* S1, float* S2, float* dW,
-                     float* db, float* dout, int64_t M, int dc, int C, hipStream_t s) {
-  if (!head_ok(dc, C)) return false;
+int head_slots() { return kHeadSlots; }
+template <int C>
+static void run_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, float* S, float* dW, float* db,
+                         float* dgamma, float* dbeta, float* dout, int64_t M, int dc, GradSlots sl, hipStream_t s) {
   const int dc4 = dc / 4, npl = 256 / dc4;
-  int64_t ppb = 1024;
-  while ((M + ppb - 1) / ppb > 1024) ppb *= 2;
-  hipLaunchKernelGGL(k_head_bwd_reduce, dim3((unsigned)((M + ppb - 1) / ppb)), dim3(256), 0, s, (const f32x4*)x, dy, W,
-                     scale, shift, mean, invstd, S1, S2, dW, db, M, dc4, C, ppb);
-  hipLaunchKernelGGL(k_head_bwd_apply, dim3(cap_grid((M + npl - 1) / npl)), dim3(256), 0, s, (const f32x4*)x, dy, W,
-                     gamma, mean, invstd, S1, S2, (f32x4*)dout, M, dc4, C);
+  int64_t ppb = 16 * npl;                                  // >= 16 pixels per thread
+  while ((M + ppb - 1) / ppb > 2048) ppb *= 2;
+  hipLaunchKernelGGL(k_head_bwd_reduce<C>, dim3((unsigned)((M + ppb - 1) / ppb)), dim3(256), 0, s, (const f32x4*)x, dy, W,
+                     scale, shift, mean, invstd, S, sl.at(dW), sl.at(db), M, dc4, ppb, sl.count(), sl.stride);
+  hipLaunchKernelGGL(k_head_bwd_apply<C>, dim3(cap_grid((M + 4 * npl - 1) / (4 * npl))), dim3(256), 0, s,
+                     (const f32x4*)x, dy, W, gamma, mean, invstd, S, (f32x4*)dout, dgamma, dbeta, M, dc4, kHeadSlots);
+}
+// S: [head_slots()][2][dc] floats, zeroed by the caller.  Adds dW, db (through the gradient slots), dgamma, dbeta.
+bool launch_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, float* S, float* dW, float* db,
+                     float* dgamma, float* dbeta, float* dout, int64_t M, int dc, int C, GradSlots sl, hipStream_t s) {
+  if (!head_ok(dc, C)) return false;
+  // the reduce pass folds S into slot (block % kHeadSlots) and dW/db into gradient slot (block % sl.count())
+  if (C == 3) run_head_bwd<3>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
+  else if (C == 1) run_head_bwd<1>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
+  else if (C == 4) run_head_bwd<4>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
+  else return false;
   return true;
 }
 

@@ -769,37 +769,49 @@ void launch_bn1d_bwd(const float* dy, const float* xhat, const float* invstd, co
 // ------------------------------------------------------------------------------------------------
 // decoder BatchNorm helpers (multiscale_vae.py:420-421)
 // ------------------------------------------------------------------------------------------------
+// sum / sqdev are `nslots` copies C floats apart (slot copies of the column statistics; copy 0 only when nslots = 1)
 __global__ void k_bn2d_finalize(const float* sum, const float* sqdev, const float* gamma, const float* beta,
                                 const float* mov_mean, const float* mov_var, float* mean, float* invstd, float* scale,
                                 float* shift, float* stat_mean, float* stat_var, float inv_m, int C, float eps,
-                                int training, int phase) {
+                                int training, int phase, int nslots) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  if (phase == 0) {   // mean from the column sums
-    mean[c] = training ? sum[c] * inv_m : mov_mean[c];
-    return;
+  float mu = 0.f;
+  if (training) {
+    for (int k = 0; k < nslots; ++k) mu += sum[k * C + c];
+    mu *= inv_m;
+  } else {
+    mu = mov_mean[c];
   }
-  float var = training ? sqdev[c] * inv_m : mov_var[c];
+  mean[c] = mu;
+  if (phase == 0) return;   // mean only
+  float var = 0.f;
+  if (training) {
+    for (int k = 0; k < nslots; ++k) var += sqdev[k * C + c];
+    var *= inv_m;
+  } else {
+    var = mov_var[c];
+  }
   float inv = rsqrtf(var + eps);
   invstd[c] = inv;
   float sc = gamma[c] * inv;
   scale[c] = sc;
-  shift[c] = beta[c] - mean[c] * sc;
-  if (training) { stat_mean[c] = mean[c]; stat_var[c] = var; }
+  shift[c] = beta[c] - mu * sc;
+  if (training) { stat_mean[c] = mu; stat_var[c] = var; }
 }
 void launch_bn2d_mean(const float* sum, const float* mov_mean, float* mean, int64_t M, int C, int training,
                       hipStream_t s) {
   ProfScope ps("bn2d_small", (double)(0.0), 0.0, s);
   hipLaunchKernelGGL(k_bn2d_finalize, dim3((C + 63) / 64), dim3(64), 0, s, sum, nullptr, nullptr, nullptr, mov_mean,
-                     nullptr, mean, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f / (float)M, C, 0.f, training, 0);
+                     nullptr, mean, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f / (float)M, C, 0.f, training, 0, 1);
 }
 void launch_bn2d_finalize(const float* sum, const float* sqdev, const float* gamma, const float* beta,
                           const float* mov_mean, const float* mov_var, float* mean, float* invstd, float* scale,
                           float* shift, float* stat_mean, float* stat_var, int64_t M, int C, float eps, int training,
-                          hipStream_t s) {
+                          int nslots, hipStream_t s) {
   ProfScope ps("bn2d_small", (double)(0.0), 0.0, s);
   hipLaunchKernelGGL(k_bn2d_finalize, dim3((C + 63) / 64), dim3(64), 0, s, sum, sqdev, gamma, beta, mov_mean, mov_var,
-                     mean, invstd, scale, shift, stat_mean, stat_var, 1.0f / (float)M, C, eps, training, 1);
+                     mean, invstd, scale, shift, stat_mean, stat_var, 1.0f / (float)M, C, eps, training, 1, nslots);
 }
 
 __global__ void k_bn2d_bwd_apply(float* __restrict__ d, const float* __restrict__ x, const float* __restrict__ mean,

@@ -4,6 +4,7 @@
 // window).  Reference: mvae/multiscale_vae.py:358-370,402-406 (Dense mu / log_var / decoder Dense),
 // mvae/layer_blocks.py:440-456 (SE Dense), :604-614 (DepthwiseConv2D).
 #include "kernels.h"
+#include "prof.h"
 
 namespace mvae {
 
@@ -344,6 +345,79 @@ bool launch_dw_wgrad_opt(const float* in, const float* dy, float* dW, float* db,
   if (C > 256 || (256 % C) != 0) return false;
   int grid = B < 512 ? B : 512;
   hipLaunchKernelGGL(k_dw_wgrad_slide, dim3(grid), dim3(256), 0, s, in, dy, dW, db, B, H, W, C);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column statistics of a [M, C] tensor, 16 bytes per lane, 8 independent loads in flight per thread.
+//   MODE 0: out[c] += sum_m x[m,c]            MODE 1: out[c] += sum_m (x[m,c] - mean[c])^2,
+// mean[c] = inv_m * sum over the `msl` slot copies of a MODE 0 result.  The block's result leaves as one atomic set into
+// slot (block % nslots) (kernels.h: GradSlots -- a few hundred blocks adding into ONE 128-byte line serialise).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256) k_colstat4(const f32x4* __restrict__ x, const float* __restrict__ msum, int msl,
+                                                  float inv_m, float* __restrict__ out, int nslots, int64_t slot_stride,
+                                                  int64_t M, int C4, int64_t rpb) {
+  __shared__ f32x4 red[4][64];
+  const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, nr = 256 / C4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 1) {
+    for (int k = 0; k < msl; ++k) mean += reinterpret_cast<const f32x4*>(msum + (int64_t)k * C4 * 4)[c4];
+    mean *= inv_m;
+  }
+  const int64_t m0 = (int64_t)blockIdx.x * rpb;
+  int64_t m1 = m0 + rpb;
+  if (m1 > M) m1 = M;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t mb = m0 + rl; mb < m1; mb += 8 * nr) {
+    f32x4 v[8];
+    float mk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t m = mb + u * nr;
+      mk[u] = m < m1 ? 1.f : 0.f;
+      v[u] = x[(m < m1 ? m : m0) * C4 + c4];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (MODE == 0) {
+        acc += v[u] * mk[u];
+      } else {
+        const f32x4 d = v[u] - mean;
+        acc += d * d * mk[u];
+      }
+    }
+  }
+  for (int off = C4; off < 64; off <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], off, 64);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (threadIdx.x < C4 * 4) {
+    const int cc = threadIdx.x >> 2, e = threadIdx.x & 3;
+    const float t = red[0][cc][e] + red[1][cc][e] + red[2][cc][e] + red[3][cc][e];
+    atomicAdd(out + (int64_t)(blockIdx.x % nslots) * slot_stride + threadIdx.x, t);
+  }
+}
+
+// false = shape not covered (C not a power-of-two multiple of 4 up to 256)
+bool launch_colstat_opt(int mode, const float* x, const float* msum, int msl, float inv_m, float* out, int nslots,
+                        int64_t slot_stride, int64_t M, int C, hipStream_t s) {
+  if (C < 4 || C > 256 || (C & (C - 1))) return false;
+  const int C4 = C / 4, nr = 256 / C4;
+  int64_t rpb = 8 * nr;                                  // one unrolled trip per thread at least
+  while ((M + rpb - 1) / rpb > 1024) rpb *= 2;
+  const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
+  ProfScope ps("col_reduce", 4.0 * M * C, 0.0, s);
+  if (mode == 0)
+    hipLaunchKernelGGL(k_colstat4<0>, dim3(grid), dim3(256), 0, s, (const f32x4*)x, msum, msl, inv_m, out,
+                       nslots < 1 ? 1 : nslots, slot_stride, M, C4, rpb);
+  else
+    hipLaunchKernelGGL(k_colstat4<1>, dim3(grid), dim3(256), 0, s, (const f32x4*)x, msum, msl, inv_m, out,
+                       nslots < 1 ? 1 : nslots, slot_stride, M, C4, rpb);
   return true;
 }
 

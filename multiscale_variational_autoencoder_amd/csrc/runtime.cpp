@@ -62,6 +62,7 @@ struct Scale {
   int dc;
   int64_t bn_g, bn_b, st_bn_mean, st_bn_var, out_w, out_b;
   float *bn_sum, *bn_sqdev, *bn_mean, *bn_invstd, *bn_scale, *bn_shift, *bn_sum_d, *bn_sum_dx;
+  float* head_S = nullptr;                  // [head_slots()][2][dc] partial BatchNorm-backward sums (kernels_edge.hip)
   float *y = nullptr, *merged = nullptr, *dy = nullptr;
   int64_t scratch_elems = 0;
   float* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -300,9 +301,14 @@ int build_plan(mvae_handle* h) {
     sc.st_bn_mean = b.state(D + ".bn.mean", ch, kDecBnMomentum, 0);
     sc.st_bn_var = b.state(D + ".bn.var", ch, kDecBnMomentum, (int64_t)H * W);
     sc.out_w = b.param(D + ".out.w", {1, 1, ch, C}, MVAE_REG_L2);   sc.out_b = b.param(D + ".out.b", {C}, 0);
-    float** small[] = {&sc.bn_sum, &sc.bn_sqdev, &sc.bn_mean, &sc.bn_invstd, &sc.bn_scale, &sc.bn_shift,
-                       &sc.bn_sum_d, &sc.bn_sum_dx};
+    float** small[] = {&sc.bn_mean, &sc.bn_invstd, &sc.bn_scale, &sc.bn_shift, &sc.bn_sum_d, &sc.bn_sum_dx};
     for (float** p : small) *p = as_ptr(b.ws_alloc(ch));
+    {   // column-statistic slot copies: [kStatSlots][ch] sums directly followed by [kStatSlots][ch] squared deviations
+      int64_t o = b.ws_alloc((int64_t)2 * kStatSlots * ch);
+      sc.bn_sum = as_ptr(o);
+      sc.bn_sqdev = as_ptr(o + (int64_t)kStatSlots * ch);
+    }
+    sc.head_S = as_ptr(b.ws_alloc((int64_t)head_slots() * 2 * ch));
     sc.y = as_ptr(b.act(D + ".y", hwC));
     sc.merged = (s == L - 1) ? sc.y : as_ptr(b.act("merged" + std::to_string(s), hwC));
     sc.dy = as_ptr(b.act("", hwC));
@@ -368,7 +374,7 @@ void rebase_all(mvae_handle* h) {
     for (Block& b : sc.dec) { rb(b.cout); rb_mn(b.mn); }
     rb(sc.mu); rb(sc.lv); rb(sc.zs); rb(sc.d0);
     rb(sc.bn_sum); rb(sc.bn_sqdev); rb(sc.bn_mean); rb(sc.bn_invstd); rb(sc.bn_scale); rb(sc.bn_shift);
-    rb(sc.bn_sum_d); rb(sc.bn_sum_dx);
+    rb(sc.bn_sum_d); rb(sc.bn_sum_dx); rb(sc.head_S);
     rb(sc.y);
     if (alias_m) sc.merged = sc.y; else rb(sc.merged);
     rb(sc.dy);
@@ -564,18 +570,20 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
     x = blk.mn.out;
   }
   const int64_t M = (int64_t)B * sc.H * sc.W;
+  // batch statistics (two-pass, multiscale_vae.py:420-421): column sums, then squared deviations, each into
+  // kStatSlots slot copies that the finalize kernel folds
   if (training) {
-    launch_zero(sc.bn_sum, (int64_t)(sc.dc), s);
-    launch_zero(sc.bn_sqdev, (int64_t)(sc.dc), s);
-    launch_colsum(x, sc.bn_sum, M, sc.dc, s);
-    launch_bn2d_mean(sc.bn_sum, nullptr, sc.bn_mean, M, sc.dc, 1, s);
-    launch_colsqdev(x, sc.bn_mean, sc.bn_sqdev, M, sc.dc, s);
-  } else {
-    launch_bn2d_mean(nullptr, h->ds + sc.st_bn_mean, sc.bn_mean, M, sc.dc, 0, s);
+    launch_zero(sc.bn_sum, (int64_t)2 * kStatSlots * sc.dc, s);               // bn_sum and bn_sqdev are adjacent
+    if (!launch_colstat_opt(0, x, nullptr, 0, 0.f, sc.bn_sum, kStatSlots, sc.dc, M, sc.dc, s))
+      launch_colsum(x, sc.bn_sum, M, sc.dc, s);
+    if (!launch_colstat_opt(1, x, sc.bn_sum, kStatSlots, 1.0f / (float)M, sc.bn_sqdev, kStatSlots, sc.dc, M, sc.dc, s)) {
+      launch_bn2d_mean(sc.bn_sum, nullptr, sc.bn_mean, M, sc.dc, 1, s);
+      launch_colsqdev(x, sc.bn_mean, sc.bn_sqdev, M, sc.dc, s);
+    }
   }
   launch_bn2d_finalize(sc.bn_sum, sc.bn_sqdev, P + sc.bn_g, P + sc.bn_b, h->ds + sc.st_bn_mean, h->ds + sc.st_bn_var,
                        sc.bn_mean, sc.bn_invstd, sc.bn_scale, sc.bn_shift, stats + sc.st_bn_mean,
-                       stats + sc.st_bn_var, M, sc.dc, kDecBnEps, training ? 1 : 0, s);
+                       stats + sc.st_bn_var, M, sc.dc, kDecBnEps, training ? 1 : 0, kStatSlots, s);
   ProfScope ps("head_fwd", 4.0 * M * (sc.dc + sc.C), 2.0 * M * sc.dc * sc.C, s);
   if (!launch_head_fwd(x, sc.bn_scale, sc.bn_shift, P + sc.out_w, P + sc.out_b, sc.y, M, sc.dc, sc.C, s)) {
     ConvGeom g = geom1x1(B, sc.H, sc.W, sc.dc, sc.C);
@@ -932,17 +940,17 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     ConvGeom go = geom1x1(B, sc.H, sc.W, sc.dc, C);
     PreOp bn{nullptr, sc.bn_scale, sc.bn_shift};
     float* d = acquire(h, sc, s);
-    launch_zero(sc.bn_sum_d, (int64_t)(sc.dc), s);
-    launch_zero(sc.bn_sum_dx, (int64_t)(sc.dc), s);
     bool fused_head;
     {
       ProfScope ps("head_bwd", 4.0 * M * (3.0 * sc.dc + 2.0 * C), 6.0 * M * sc.dc * C, s);
+      launch_zero(sc.head_S, (int64_t)head_slots() * 2 * sc.dc, s);
       fused_head = launch_head_bwd(xbn, sc.dy, P + sc.out_w, P + sc.bn_g, sc.bn_scale, sc.bn_shift, sc.bn_mean,
-                                   sc.bn_invstd, sc.bn_sum_d, sc.bn_sum_dx, G + sc.out_w, G + sc.out_b, d, M, sc.dc, C, s);
+                                   sc.bn_invstd, sc.head_S, G + sc.out_w, G + sc.out_b, G + sc.bn_g, G + sc.bn_b, d, M,
+                                   sc.dc, C, h->gslots, s);
     }
-    if (fused_head) {
-      launch_add_vec2(G + sc.bn_g, sc.bn_sum_dx, G + sc.bn_b, sc.bn_sum_d, sc.dc, s);
-    } else {
+    if (!fused_head) {
+      launch_zero(sc.bn_sum_d, (int64_t)(sc.dc), s);
+      launch_zero(sc.bn_sum_dx, (int64_t)(sc.dc), s);
       launch_conv_wgrad(xbn, sc.dy, G + sc.out_w, G + sc.out_b, go, bn, s);
       launch_conv_t(sc.dy, P + sc.out_w, nullptr, nullptr, d, go, s);
       launch_bn_bwd_reduce(d, xbn, sc.bn_mean, sc.bn_invstd, sc.bn_sum_d, sc.bn_sum_dx, M, sc.dc, s);
@@ -960,7 +968,9 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
         {
           hipStream_t w = wgrad_begin(h, sc, s);
           launch_conv_wgrad(d, prev, G + blk.cw, nullptr, g, none, w);
-          launch_colsum(d, G + blk.cb, (int64_t)B * g.IH * g.IW, g.CI, w);
+          if (!launch_colstat_opt(0, d, nullptr, 0, 0.f, h->gslots.at(G + blk.cb), h->gslots.count(), h->gslots.stride,
+                                  (int64_t)B * g.IH * g.IW, g.CI, w))
+            launch_colsum(d, G + blk.cb, (int64_t)B * g.IH * g.IW, g.CI, w);
           wgrad_reads(h, sc, d, w);
         }
         float* n = acquire(h, sc, s);
