@@ -180,6 +180,16 @@ bool launch_convbase_wgrad(const float* in, const float* dy, const float* y, flo
                            int CI, int CO, hipStream_t s);
 bool launch_head_fwd(const float* x, const float* scale, const float* shift, const float* W, const float* bias,
                      float* y, int64_t M, int dc, int C, hipStream_t s);
+// squeeze-excite branch in two forward / two backward launches (kernels_se.hip); part: [se_max_blocks(B)][2][C] floats
+int se_max_blocks(int max_batch);
+bool launch_se_forward(const float* gap, const float* W0, const float* b0, const float* gamma, const float* beta,
+                       const float* mov_mean, const float* mov_var, const float* W1, const float* b1, float* s0,
+                       float* xhat, float* invstd, float* ulin, float* g, float* stat_mean, float* stat_var,
+                       float* part, int B, int C, float eps, int training, hipStream_t s);
+bool launch_se_backward(const float* dg, const float* ulin, const float* xhat, const float* invstd, const float* gamma,
+                        const float* beta, const float* s0, const float* gap, const float* W1, const float* W0,
+                        float* ds1, float* dgap, float* dW1, float* db1, float* dgamma, float* dbeta, float* dW0,
+                        float* db0, float* part, int B, int C, GradSlots sl, hipStream_t s);
 int head_slots();
 // S: [head_slots()][2][dc] floats, zeroed by the caller; adds dW, db (gradient slots), dgamma, dbeta
 bool launch_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,

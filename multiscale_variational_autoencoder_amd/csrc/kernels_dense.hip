@@ -322,7 +322,7 @@ bool launch_dense_expand(const float* z, const float* W, const float* bias, floa
 bool launch_dense_wgrad_mu_lv(const float* flat, const float* dmu, const float* dlv, float* dWmu, float* dWlv,
                               float* dbmu, float* dblv, int B, int K, int Z, hipStream_t s) {
   if (2 * Z > 32) return false;
-  if (K >= 1024) {
+  if (K >= 64) {
     hipLaunchKernelGGL(k_dense_wgrad_mfma, dim3((K + 31) / 32), dim3(256), 0, s, flat, dmu, dlv, dWmu, dWlv, dbmu,
                        dblv, B, K, Z);
     return true;

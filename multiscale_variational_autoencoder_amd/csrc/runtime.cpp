@@ -41,6 +41,7 @@ struct MN {
   int64_t st_mean, st_var;
   float *t0 = nullptr, *t1 = nullptr, *out = nullptr;
   float *gap = nullptr, *s0 = nullptr, *xhat = nullptr, *s1 = nullptr, *ulin = nullptr, *g = nullptr, *invstd = nullptr;
+  float* se_part = nullptr;                 // [se_max_blocks][2][c] per-block partial statistics (kernels_se.hip)
 };
 struct Block {
   bool has_conv = false;
@@ -210,6 +211,7 @@ void build_mn(Builder& b, MN& m, const std::string& p, int c, int H, int W, Scal
   m.ulin = as_ptr(b.act(p + ".ulin", c));
   m.g = as_ptr(b.act(p + ".g", c));
   m.invstd = as_ptr(b.ws_alloc(c));
+  m.se_part = as_ptr(b.ws_alloc((int64_t)se_max_blocks(b.maxB) * 2 * c));
   if (hwc > sc.scratch_elems) sc.scratch_elems = hwc;
   if (c > sc.cmax) sc.cmax = c;
 }
@@ -363,7 +365,7 @@ void rebase_all(mvae_handle* h) {
   float* base = h->ws;
   auto rb = [&](float*& p) { p = rebase(p, base); };
   auto rb_mn = [&](MN& m) {
-    rb(m.t0); rb(m.t1); rb(m.out); rb(m.gap); rb(m.s0); rb(m.xhat); rb(m.s1); rb(m.ulin); rb(m.g); rb(m.invstd);
+    rb(m.t0); rb(m.t1); rb(m.out); rb(m.gap); rb(m.s0); rb(m.xhat); rb(m.s1); rb(m.ulin); rb(m.g); rb(m.invstd); rb(m.se_part);
   };
   for (Scale& sc : h->scales) {
     bool alias_band = sc.band == sc.pcur, alias_m = sc.merged == sc.y;
@@ -471,10 +473,14 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
     launch_dw_fwd(m.t0, P + m.wd, P + m.bd, m.t1, B, m.H, m.W, c, s);
     launch_spatial_sum(m.t1, m.gap, B, (int64_t)m.H * m.W, c, 1.0f / (float)(m.H * m.W), s);
   }
-  launch_gemm_nn(m.gap, P + m.sw0, P + m.sb0, m.s0, nullptr, B, c, c, ACT_RELU, s);
-  launch_bn1d_fwd(m.s0, P + m.gam, P + m.bet, h->ds + m.st_mean, h->ds + m.st_var, m.xhat, m.invstd, m.s1,
-                  stats + m.st_mean, stats + m.st_var, B, c, kSeBnEps, training ? 1 : 0, s);
-  launch_gemm_nn(m.s1, P + m.sw1, P + m.sb1, m.g, m.ulin, B, c, c, ACT_HSIG, s);
+  if (!launch_se_forward(m.gap, P + m.sw0, P + m.sb0, P + m.gam, P + m.bet, h->ds + m.st_mean, h->ds + m.st_var,
+                         P + m.sw1, P + m.sb1, m.s0, m.xhat, m.invstd, m.ulin, m.g, stats + m.st_mean,
+                         stats + m.st_var, m.se_part, B, c, kSeBnEps, training ? 1 : 0, s)) {
+    launch_gemm_nn(m.gap, P + m.sw0, P + m.sb0, m.s0, nullptr, B, c, c, ACT_RELU, s);
+    launch_bn1d_fwd(m.s0, P + m.gam, P + m.bet, h->ds + m.st_mean, h->ds + m.st_var, m.xhat, m.invstd, m.s1,
+                    stats + m.st_mean, stats + m.st_var, B, c, kSeBnEps, training ? 1 : 0, s);
+    launch_gemm_nn(m.s1, P + m.sw1, P + m.sb1, m.g, m.ulin, B, c, c, ACT_HSIG, s);
+  }
   PreOp gate{m.g, nullptr, nullptr};
   launch_conv_f(m.t1, P + m.w2, P + m.b2, x, m.out, g, gate, ACT_NONE, s);
 }
@@ -505,17 +511,21 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
     }
     launch_conv_t_dot(dout, P + m.w2, bufB, m.t1, sc.dg, g, s);        // dt2 = dout . W2^T ; dg = sum_hw dt2 * t1
   }
-  // squeeze-excite backward
-  {
-    ProfScope ps("k_se_pair", 16.0 * B * c, 4.0 * B * c * c, s);
-    // du = dg * hsig'(u):  dW1 += s1^T du, db1 += sum du  and  ds1 = du W1^T   (s1 = gamma*xhat + beta)
-    launch_se_pair(m.xhat, sc.dg, P + m.sw1, G + m.sw1, G + m.sb1, sc.ds1, B, c, c, P + m.gam, P + m.bet, m.ulin, s);
-  }
-  launch_bn1d_bwd(sc.ds1, m.xhat, m.invstd, P + m.gam, m.s0, sc.dv, G + m.gam, G + m.bet, B, c, s);
-  {
-    ProfScope ps("k_se_pair", 16.0 * B * c, 4.0 * B * c * c, s);
-    // dW0 += gap^T dv, db0 += sum dv  and  dgap = dv W0^T
-    launch_se_pair(m.gap, sc.dv, P + m.sw0, G + m.sw0, G + m.sb0, sc.dgap, B, c, c, nullptr, nullptr, nullptr, s);
+  // squeeze-excite backward: dg -> (dW1, db1, dgamma, dbeta, dW0, db0) and dgap
+  if (!launch_se_backward(sc.dg, m.ulin, m.xhat, m.invstd, P + m.gam, P + m.bet, m.s0, m.gap, P + m.sw1, P + m.sw0, sc.ds1,
+                          sc.dgap, G + m.sw1, G + m.sb1, G + m.gam, G + m.bet, G + m.sw0, G + m.sb0, m.se_part, B, c,
+                          h->gslots, s)) {
+    {
+      ProfScope ps("k_se_pair", 16.0 * B * c, 4.0 * B * c * c, s);
+      // du = dg * hsig'(u):  dW1 += s1^T du, db1 += sum du  and  ds1 = du W1^T   (s1 = gamma*xhat + beta)
+      launch_se_pair(m.xhat, sc.dg, P + m.sw1, G + m.sw1, G + m.sb1, sc.ds1, B, c, c, P + m.gam, P + m.bet, m.ulin, s);
+    }
+    launch_bn1d_bwd(sc.ds1, m.xhat, m.invstd, P + m.gam, m.s0, sc.dv, G + m.gam, G + m.bet, B, c, s);
+    {
+      ProfScope ps("k_se_pair", 16.0 * B * c, 4.0 * B * c * c, s);
+      // dW0 += gap^T dv, db0 += sum dv  and  dgap = dv W0^T
+      launch_se_pair(m.gap, sc.dv, P + m.sw0, G + m.sw0, G + m.sb0, sc.dgap, B, c, c, nullptr, nullptr, nullptr, s);
+    }
   }
   // through the gate multiply, the global average pool and the depthwise ReLU
   float* bufC = acquire(h, sc, s);
