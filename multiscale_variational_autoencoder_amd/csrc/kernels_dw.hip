@@ -36,52 +36,68 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const f32x4* __restrict__ i
   f32x4* oimg = out + (int64_t)b * g.H * g.W * g.C4;
   const int row_items = XSP * g.C4;
 
-  // rows are fetched into registers one iteration before they are stored to the ring (see k_dw_bwd_ring)
-  f32x4 rv[3];
-  auto fetch_row = [&](int y) {
+  // Rows travel HBM -> registers -> LDS ring.  A row is fetched FOUR iterations before it is stored to the ring (a
+  // register FIFO of four rows, statically indexed by unrolling the row loop by four): with one or two resident blocks
+  // per CU the bytes in flight per CU -- not the arithmetic -- set the rate of this kernel.
+  f32x4 rv[4][3];
+  auto fetch_row = [&](int y, f32x4 (&r)[3]) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int t = threadIdx.x + 256 * u;
-      rv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < row_items) {
-        const int x = x0 - 1 + t / g.C4;
-        if (x >= 0 && x < g.W) rv[u] = img[((int64_t)y * g.W + x) * g.C4 + c4];
-      }
+      const int x = x0 - 1 + t / g.C4;
+      const bool ok = t < row_items && x >= 0 && x < g.W;
+      r[u] = img[ok ? ((int64_t)y * g.W + x) * g.C4 + c4 : 0];               // RAW: clamped, unconditional
     }
   };
-  auto store_row = [&](int y) {                       // row y (with column halo) -> ring slot y & 3
+  auto store_row = [&](int y, const f32x4 (&r)[3]) {  // row y (with column halo) -> ring slot y & 3; halo zeroed here
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int t = threadIdx.x + 256 * u;
-      if (t < row_items) RING(y & 3, t / g.C4, c4) = rv[u];
+      const int x = x0 - 1 + t / g.C4;
+      const bool ok = x >= 0 && x < g.W;
+      if (t < row_items) RING(y & 3, t / g.C4, c4) = ok ? r[u] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   f32x4 gsum[2];
   gsum[0] = gsum[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  fetch_row(0); store_row(0);
-  if (g.H > 1) fetch_row(1);
-  for (int y = 0; y < g.H; ++y) {
-    if (y + 1 < g.H) store_row(y + 1);
-    if (y + 2 < g.H) fetch_row(y + 2);
-    __syncthreads();
+  // H % 4 == 0 (launcher): the body below is straight-line code -- no uniform branches around the loads, so the
+  // compiler counts the outstanding loads exactly (s_waitcnt vmcnt(N), N > 0) instead of draining them.  Rows past the
+  // image are clamped to the last row: fetched and stored to a ring slot nobody reads.
+  const int yl = g.H - 1;
+  fetch_row(0, rv[0]);
+  fetch_row(1, rv[1]);
+  fetch_row(2, rv[2]);
+  fetch_row(3, rv[3]);
+  store_row(0, rv[0]);
+  fetch_row(min(4, yl), rv[0]);
+  for (int yb = 0; yb < g.H; yb += 4) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int idx = threadIdx.x + 256 * k;
-      if (idx < items) {
-        const int xl = idx / g.C4;                    // local column, image column x0 + xl, ring column xl + 1
-        if (xl < xs_n) {
-          f32x4 acc = bs;
+    for (int u4 = 0; u4 < 4; ++u4) {
+      const int y = yb + u4;
+      {
+        store_row(y + 1, rv[(u4 + 1) & 3]);
+        fetch_row(min(y + 5, yl), rv[(u4 + 1) & 3]);
+        __syncthreads();
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const int yy = y + a - 1;
-            if (yy < 0 || yy >= g.H) continue;
+        for (int k = 0; k < 2; ++k) {
+          const int idx = threadIdx.x + 256 * k;
+          if (idx < items) {
+            const int xl = idx / g.C4;                // local column, image column x0 + xl, ring column xl + 1
+            if (xl < xs_n) {
+              f32x4 acc = bs;
 #pragma unroll
-            for (int e = 0; e < 3; ++e) acc += wt[a * 3 + e] * RING(yy & 3, xl + e, c4);
+              for (int a = 0; a < 3; ++a) {
+                const int yy = y + a - 1;
+                if (yy < 0 || yy >= g.H) continue;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) acc += wt[a * 3 + e] * RING(yy & 3, xl + e, c4);
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[q] = acc[q] > 0.f ? acc[q] : 0.f;
+              oimg[((int64_t)y * g.W + x0 + xl) * g.C4 + c4] = acc;
+              if (FUSE_GAP) gsum[k] += acc;
+            }
           }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = acc[q] > 0.f ? acc[q] : 0.f;
-          oimg[((int64_t)y * g.W + x0 + xl) * g.C4 + c4] = acc;
-          if (FUSE_GAP) gsum[k] += acc;
         }
       }
     }
@@ -110,8 +126,9 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const f32x4* __restrict__ i
 __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ dt2, const f32x4* __restrict__ t1,
                                                      const f32x4* __restrict__ t0, const f32x4* __restrict__ w,
                                                      const f32x4* __restrict__ gate, const f32x4* __restrict__ dgap,
-                                                     f32x4* __restrict__ dt0, f32x4* __restrict__ partial, DwGeom g,
-                                                     float inv_hw, int B, int RS, int nseg) {
+                                                     f32x4* __restrict__ dt0, float* __restrict__ dW,
+                                                     float* __restrict__ db, DwGeom g, float inv_hw, int B, int RS,
+                                                     int nseg, int nslots, int64_t slot_stride) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   f32x4* ring = reinterpret_cast<f32x4*>(dyn_lds);
   const int XSP = g.XS + 2;
@@ -132,114 +149,116 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
     const int b = item / nseg, seg = item % nseg;
     const int ya = seg * RS, yb = min(g.H, ya + RS);
     const int64_t ioff = (int64_t)b * g.H * g.W * g.C4;
-    // a row of d1 is fetched in two steps: raw loads into registers (issued two rows ahead), and -- one iteration
-    // later, after the compute of the current row -- the gate/ReLU arithmetic and the LDS store.  row_items <= 3*256.
-    f32x4 rd[3], ra[3];
+    // A row of d1 takes two steps: RAW loads of (dt2, t1) into a two-slot register FIFO, issued two iterations before
+    // the row is needed, and -- at the top of the iteration that needs it -- the gate / GAP / ReLU arithmetic and the
+    // LDS store.  t0 rows ride a second two-slot FIFO.  The row loop is unrolled by two (static slots) and is
+    // straight-line code (clamped addresses, RS even): the compiler then waits with exact vmcnt(N) counts and the
+    // loads of the next two rows stay in flight under the current row's arithmetic.
+    f32x4 Fd[2][3], Fa[2][3], T[2][2];
     const f32x4 gg_c = gate[(int64_t)b * g.C4 + c4];       // (row_items % C4 == 0 and 256 % C4 == 0: cc == c4)
     const f32x4 dg_c = dgap[(int64_t)b * g.C4 + c4] * inv_hw;
-    auto fetch_row = [&](int y) {
+    const int ybc = min(yb, g.H - 1);                      // last d1 row this item needs
+    auto fetch_row = [&](int y, f32x4 (&rd)[3], f32x4 (&ra)[3]) {
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int t = threadIdx.x + 256 * u;
-        rd[u] = ra[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t < row_items) {
-          const int x = x0 - 1 + t / g.C4;
-          if (x >= 0 && x < g.W) {
-            const int64_t o = ioff + ((int64_t)y * g.W + x) * g.C4 + c4;
-            rd[u] = dt2[o]; ra[u] = t1[o];
-          }
-        }
+        const int x = x0 - 1 + t / g.C4;
+        const bool ok = t < row_items && x >= 0 && x < g.W;
+        const int64_t o = ok ? ioff + ((int64_t)y * g.W + x) * g.C4 + c4 : 0;
+        rd[u] = dt2[o];
+        ra[u] = t1[o];
       }
     };
-    auto store_row = [&](int y) {                     // d1 row y (with column halo) -> ring slot y & 3
+    auto store_row = [&](int y, const f32x4 (&rd)[3], const f32x4 (&ra)[3]) {   // d1 row y (+ halo) -> ring slot y & 3
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int t = threadIdx.x + 256 * u;
+        const int x = x0 - 1 + t / g.C4;
+        const bool ok = x >= 0 && x < g.W;
         if (t < row_items) {
           f32x4 v;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = ra[u][q] > 0.f ? rd[u][q] * gg_c[q] + dg_c[q] : 0.f;
+          for (int q = 0; q < 4; ++q) v[q] = (ok && ra[u][q] > 0.f) ? rd[u][q] * gg_c[q] + dg_c[q] : 0.f;
           RING(y & 3, t / g.C4, c4) = v;
         }
       }
     };
+    auto fetch_t0 = [&](int y, f32x4 (&tv)[2]) {
+      tv[0] = t0[has0 ? ioff + ((int64_t)y * g.W + x0 + xl0) * g.C4 + c4 : 0];
+      tv[1] = t0[has1 ? ioff + ((int64_t)y * g.W + x0 + xl1) * g.C4 + c4 : 0];
+    };
     __syncthreads();                                  // previous item's ring reads are done
-    if (ya > 0) { fetch_row(ya - 1); store_row(ya - 1); }
-    fetch_row(ya); store_row(ya);
-    if (ya + 1 < g.H) fetch_row(ya + 1);              // in flight across the first iteration
-    for (int y = ya; y < yb; ++y) {
-      // t0 of this row is independent of the ring: issue it before the barrier so both latencies overlap
-      const int64_t o0 = ioff + ((int64_t)y * g.W + x0 + xl0) * g.C4 + c4;
-      const int64_t o1 = ioff + ((int64_t)y * g.W + x0 + xl1) * g.C4 + c4;
-      f32x4 tv[2];
-      tv[0] = has0 ? t0[o0] : f32x4{0.f, 0.f, 0.f, 0.f};
-      tv[1] = has1 ? t0[o1] : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (y + 1 < g.H) store_row(y + 1);              // fetched during the previous iteration
-      if (y + 2 < g.H && y + 1 < yb) fetch_row(y + 2);
-      __syncthreads();
+    // prologue: d1 rows ya-1 (for ya = 0: a copy of row 0 in a slot nobody reads) and ya go to the ring at once
+    fetch_row(max(ya - 1, 0), Fd[0], Fa[0]);
+    fetch_row(ya, Fd[1], Fa[1]);
+    fetch_t0(ya, T[0]);
+    fetch_t0(min(ya + 1, yb - 1), T[1]);
+    store_row(ya - 1, Fd[0], Fa[0]);
+    store_row(ya, Fd[1], Fa[1]);
+    fetch_row(min(ya + 1, ybc), Fd[1], Fa[1]);
+    fetch_row(min(ya + 2, ybc), Fd[0], Fa[0]);
+    for (int y2 = ya; y2 < yb; y2 += 2) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        if (k == 0 ? has0 : has1) {
+      for (int kk = 0; kk < 2; ++kk) {
+        const int y = y2 + kk;
+        store_row(y + 1, Fd[(kk + 1) & 1], Fa[(kk + 1) & 1]);
+        fetch_row(min(y + 3, ybc), Fd[(kk + 1) & 1], Fa[(kk + 1) & 1]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const bool has = k == 0 ? has0 : has1;
           const int xl = k == 0 ? xl0 : xl1;
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          // position (y,x) was read by output pixel (y-a+1, x-e+1) through tap (a,e)
+          const f32x4 tvk = has ? T[kk][k] : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (has) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // position (y,x) was read by output pixel (y-a+1, x-e+1) through tap (a,e)
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const int yy = y - a + 1;
-            if (yy < 0 || yy >= g.H) continue;
+            for (int a = 0; a < 3; ++a) {
+              const int yy = y - a + 1;
+              if (yy < 0 || yy >= g.H) continue;
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
-              const f32x4 sv = RING(yy & 3, xl + 2 - e, c4);     // column x - e + 1 -> ring column xl + 2 - e
-              acc += wt[a * 3 + e] * sv;
-              aw[a * 3 + e] += tv[k] * sv;
+              for (int e = 0; e < 3; ++e) {
+                const f32x4 sv = RING(yy & 3, xl + 2 - e, c4);     // column x - e + 1 -> ring column xl + 2 - e
+                acc += wt[a * 3 + e] * sv;
+                aw[a * 3 + e] += tvk * sv;
+              }
             }
-          }
-          ab += RING(y & 3, xl + 1, c4);
-          f32x4 r;
+            ab += RING(y & 3, xl + 1, c4);
+            f32x4 r;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) r[q] = tv[k][q] > 0.f ? acc[q] : 0.f;
-          dt0[k == 0 ? o0 : o1] = r;
+            for (int q = 0; q < 4; ++q) r[q] = tvk[q] > 0.f ? acc[q] : 0.f;
+            dt0[ioff + ((int64_t)y * g.W + x0 + xl) * g.C4 + c4] = r;
+          }
         }
+        fetch_t0(min(y + 2, yb - 1), T[kk]);
       }
     }
   }
-  // ---- block reduction of the 10 float4 accumulators over the threads that share c4; the block's partial goes
-  //      out with plain stores (summed by k_dw_partials: deterministic, no contended float atomics)
-  f32x4* red = ring;                                  // needs 256 float4 = 4 KB <= ring size (checked by launcher)
-  f32x4* pout = partial + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 10 * g.C4;
+  // ---- block reduction of the 10 float4 accumulators over the threads that share c4 (wave shuffles, then the 4 waves
+  //      through LDS); the block's sums leave as one atomic set into gradient slot (block % nslots) (kernels.h)
+  __syncthreads();
+  f32x4* red = ring;                                  // needs 4 * 10 * C4 float4 <= ring size (checked by launcher)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 10; ++k) {
-    __syncthreads();
-    red[threadIdx.x] = k < 9 ? aw[k < 9 ? k : 0] : ab;
-    __syncthreads();
-    if (threadIdx.x < g.C4) {
-      f32x4 t = {0.f, 0.f, 0.f, 0.f};
-      for (int r = threadIdx.x; r < 256; r += g.C4) t += red[r];
-      pout[k * g.C4 + threadIdx.x] = t;
+    f32x4 v = k < 9 ? aw[k < 9 ? k : 0] : ab;
+    for (int off = g.C4; off < 64; off <<= 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += __shfl_xor(v[q], off, 64);
     }
+    if (lane < g.C4 && lane < 64) red[(wave * 10 + k) * g.C4 + lane] = v;
+  }
+  __syncthreads();
+  const int wpc = 4;                                  // C4 <= 64 (launcher): every wave holds all C4 columns
+  const int64_t slot = (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) % nslots) * slot_stride;
+  for (int idx = threadIdx.x; idx < 10 * g.C4 * 4; idx += 256) {
+    const int q = idx & 3, cc = (idx >> 2) % g.C4, k = (idx >> 2) / g.C4;
+    float t = 0.f;
+    for (int wv = 0; wv < wpc; ++wv) t += red[(wv * 10 + k) * g.C4 + cc][q];
+    atomicAdd((k < 9 ? dW + slot + (int64_t)k * g.C4 * 4 : db + slot) + cc * 4 + q, t);
   }
 }
 
-// dW[k][c] += sum_blocks partial[blk][k][c] (k < 9) ; db[c] += sum_blocks partial[blk][9][c]
-// blockIdx.y splits the block axis into 32 chunks (each thread sums <= nblk/32 partials, then one float atomic)
-__global__ void __launch_bounds__(256) k_dw_partials(const float* __restrict__ partial, int nblk, float* __restrict__ dW,
-                                                     float* __restrict__ db, int C) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 10 * C) return;
-  const int per = (nblk + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
-  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-  int bk = b0;
-  for (; bk + 3 < b1; bk += 4) {
-    t0 += partial[(int64_t)bk * 10 * C + i];
-    t1 += partial[(int64_t)(bk + 1) * 10 * C + i];
-    t2 += partial[(int64_t)(bk + 2) * 10 * C + i];
-    t3 += partial[(int64_t)(bk + 3) * 10 * C + i];
-  }
-  for (; bk < b1; ++bk) t0 += partial[(int64_t)bk * 10 * C + i];
-  const float t = (t0 + t1) + (t2 + t3);
-  if (b1 > b0) atomicAdd(i < 9 * C ? &dW[i] : &db[i - 9 * C], t);
-}
 #undef RING
 
 static bool dw_geom(int H, int W, int C, DwGeom* g, size_t* lds) {
@@ -260,7 +279,7 @@ bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* o
                        int C, hipStream_t s) {
   DwGeom g;
   size_t lds;
-  if (!dw_geom(H, W, C, &g, &lds) || B > 65535) return false;
+  if (!dw_geom(H, W, C, &g, &lds) || B > 65535 || (H % 4) != 0) return false;
   if (g.strips > 1) launch_zero(gap, (int64_t)B * C, s);
   hipLaunchKernelGGL(k_dw_fwd_ring<true>, dim3(g.strips, B), dim3(256), lds, s, (const f32x4*)in, (const f32x4*)w,
                      (const f32x4*)b, (f32x4*)out, gap, g, 1.0f / (float)(H * W));
@@ -270,23 +289,25 @@ bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* o
 // fused backward through Multiply/GAP/ReLU + depthwise backward-data + depthwise weight/bias gradients.
 // `partial` is a scratch buffer of kDwMaxBlocks * 10 * C floats.
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
-                         const float* dgap, float* dt0, float* dW, float* db, float* partial, int B, int H, int W,
-                         int C, hipStream_t s) {
+                         const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, int B, int H, int W, int C,
+                         hipStream_t s) {
   DwGeom g;
   size_t lds;
-  if (!dw_geom(H, W, C, &g, &lds) || !partial) return false;
-  // split images into row segments until ~2048 work items exist (each costs two halo rows of re-reads)
+  if (!dw_geom(H, W, C, &g, &lds) || g.C4 > 64) return false;
+  const size_t red_bytes = (size_t)40 * g.C4 * sizeof(f32x4);          // 4 waves x 10 accumulators x C4
+  if (lds < red_bytes) lds = red_bytes;
+  // split images into row segments until ~1024 work items exist (each costs two halo rows of re-reads and one
+  // exposed prologue); the kernel needs an even number of rows per segment
+  if (H % 2) return false;
   int nseg = 1;
-  while ((int64_t)B * g.strips * nseg < 2048 && H / (nseg * 2) >= 2) nseg *= 2;
-  const int RS = (H + nseg - 1) / nseg;
-  nseg = (H + RS - 1) / RS;
+  while ((int64_t)B * g.strips * nseg < 1024 && (H / (nseg * 2)) % 2 == 0 && H / (nseg * 2) >= 4) nseg *= 2;
+  const int RS = H / nseg;
   int64_t work = (int64_t)B * nseg;
   int gy = (int)(work < kDwMaxBlocks / g.strips ? work : kDwMaxBlocks / g.strips);
   if (gy < 1) return false;
   hipLaunchKernelGGL(k_dw_bwd_ring, dim3(g.strips, gy), dim3(256), lds, s, (const f32x4*)dt2, (const f32x4*)t1,
-                     (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0,
-                     (f32x4*)partial, g, 1.0f / (float)(H * W), B, RS, nseg);
-  hipLaunchKernelGGL(k_dw_partials, dim3((10 * C + 255) / 256, 32), dim3(256), 0, s, partial, g.strips * gy, dW, db, C);
+                     (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0, sl.at(dW),
+                     sl.at(db), g, 1.0f / (float)(H * W), B, RS, nseg, sl.count(), sl.stride);
   return true;
 }
 

@@ -532,7 +532,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   bool fused_dw;
   {
     ProfScope ps("k_dw_bwd_ring", 16.0 * B * HW * c, 40.0 * B * HW * c, s);
-    fused_dw = launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC, G + m.wd, G + m.bd, sc.dw_part, B, m.H,
+    fused_dw = launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC, G + m.wd, G + m.bd, h->gslots, B, m.H,
                                    m.W, c, s);
   }
   if (!fused_dw) {
