@@ -16,6 +16,14 @@
 
 namespace mvae {
 
+// Blocks of the persistent (grid-stride) kernels: two register-limited workgroups per CU on `big_grid_cus()` CUs.
+// Fewer than all 256 CUs leaves slots where the short kernels of the other pyramid scales (own HIP streams) can start
+// at once instead of waiting for a persistent block to retire.
+static int big_grid_cus() {
+  static const int v = [] { const char* e = getenv("MVAE_BIG_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  return v;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -181,7 +189,9 @@ static void run_gemm_rows(const float* X, const float* W, const float* bias, con
                           int64_t M, int64_t rows_per_image, PreOp pre, int act, const float* dot_src, float* dot_out,
                           hipStream_t s) {
   int64_t ntiles = (M + 127) / 128;
-  int grid = (int)(ntiles < 512 ? ntiles : 512);     // 256 CUs x 2 resident workgroups (register-limited)
+  static const int rows_cap = [] { const char* e = getenv("MVAE_ROWS_GRID"); return e ? atoi(e) : 0; }();
+  const int cap = rows_cap > 0 ? rows_cap : 2 * big_grid_cus();   // 2 resident workgroups per CU (register-limited)
+  int grid = (int)(ntiles < cap ? ntiles : cap);
   hipLaunchKernelGGL((k_gemm_rows<K, N, WT>), dim3(grid), dim3(256), 0, s, X, W, bias, residual, Y, M, rows_per_image,
                      pre, act, dot_src, dot_out);
 }
@@ -620,7 +630,11 @@ template <int KC, int NC, bool TFORM>
 __global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in, const float* __restrict__ W,
                                                    const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
   constexpr int KHF = KC / 2, NT = NC / 32, Q = KHF / 4;
-  __shared__ __attribute__((aligned(16))) float sW[2][KC * NC];
+  // T-form stages W[tap][n][k] transposed (consecutive threads -> consecutive k): a row pitch of NC + 1 keeps those
+  // stores conflict-free (pitch NC put all 32 lanes of a store on one bank: 85 % of the kernel's LDS cycles were bank
+  // conflicts); the fragment reads (lanes along n) are conflict-free for either pitch
+  constexpr int WP = TFORM ? NC + 1 : NC;
+  __shared__ __attribute__((aligned(16))) float sW[2][KC * WP];
   __shared__ int64_t sOff[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -656,19 +670,23 @@ __global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in,
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
+  // The next tap's weight slice travels global -> registers (issued BEFORE this tap's MFMAs) -> LDS (written AFTER
+  // them): the L2 latency of the weight loads hides under the MFMAs instead of stalling them at an LDS write.
   constexpr int WPT = KC * NC / 256;                     // weights per thread per tap
-  auto stage_w = [&](int it, int buf) {
+  float wtmp[WPT];
+  auto fetch_w = [&](int it) {
     const int kh = kh0 + (it / nkw) * khs, kw = kw0 + (it % nkw) * kws;
     const float* wt = W + (int64_t)(kh * g.KW + kw) * KC * NC;
-    float tmp[WPT];                                      // all loads first, then the LDS writes
 #pragma unroll
-    for (int u = 0; u < WPT; ++u) tmp[u] = wt[threadIdx.x + u * 256];
+    for (int u = 0; u < WPT; ++u) wtmp[u] = wt[threadIdx.x + u * 256];
+  };
+  auto store_w = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < WPT; ++u) {
       const int idx = threadIdx.x + u * 256;
       // sW[k][n]; F: W[tap][k][n] as stored; T: W[tap][n][k]
-      if (TFORM) { int n = idx / KC, k = idx % KC; sW[buf][k * NC + n] = tmp[u]; }
-      else sW[buf][idx] = tmp[u];
+      if (TFORM) { int n = idx / KC, k = idx % KC; sW[buf][k * WP + n] = wtmp[u]; }
+      else sW[buf][idx] = wtmp[u];
     }
   };
   f32x4 a_next[Q];
@@ -694,13 +712,15 @@ __global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in,
     }
   };
 
-  if (ntaps > 0) { stage_w(0, 0); load_a(0); }
+  if (ntaps > 0) { fetch_w(0); load_a(0); store_w(0); }
   for (int it = 0; it < ntaps; ++it) {
-    __syncthreads();
+    __syncthreads();       // sW[it & 1] is complete; every wave has finished reading sW[(it + 1) & 1]
     f32x4 a[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) a[q] = a_next[q];
-    if (it + 1 < ntaps) { stage_w(it + 1, (it + 1) & 1); load_a(it + 1); }
+    const bool more = it + 1 < ntaps;
+    if (more) { fetch_w(it + 1); load_a(it + 1); }
+    __builtin_amdgcn_sched_barrier(0);
     const float* w = sW[it & 1];
 #pragma unroll
     for (int q = 0; q < Q; ++q)
@@ -709,8 +729,10 @@ __global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in,
         const int k = h * KHF + q * 4 + e;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], w[k * NC + nt * 32 + i], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], w[k * WP + nt * 32 + i], acc[nt], 0, 0, 0);
       }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) store_w((it + 1) & 1);
   }
   __syncthreads();     // sOff visible (also when ntaps == 0)
 #pragma unroll
@@ -829,6 +851,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
     }
     __syncthreads();
     if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);          // prefetch under the MFMAs
+    // the residual is fetched in the accumulator layout BEFORE both MFMA phases: its HBM latency (2-3 us under load)
+    // is longer than one phase
+    const int64_t left = M - row0 - 4 * h;
+    const int lim = left < 32 ? (int)left : 32;            // row (r&3)+8(r>>2) of this lane half is valid below lim
+    const int64_t ebase = (row0 + 4 * h) * C + n0 + i;
+    float res[16];
+    if (residual) {
+      const float* pr = residual + ebase;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) res[r] = pr[((r & 3) + 8 * (r >> 2)) < lim ? ((r & 3) + 8 * (r >> 2)) * C : 0];
+    }
     // ---- Y tile = X . Wt   (32 rows x 32 columns per wave)
     f32x16 acc;
 #pragma unroll
@@ -843,16 +876,6 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
       for (int q = 0; q < KH / 4; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[q * 4 + e], acc, 0, 0, 0);
-    }
-    // the residual is fetched in the accumulator layout, a whole MFMA phase ahead of its use
-    const int64_t left = M - row0 - 4 * h;
-    const int lim = left < 32 ? (int)left : 32;            // row (r&3)+8(r>>2) of this lane half is valid below lim
-    const int64_t ebase = (row0 + 4 * h) * C + n0 + i;
-    float res[16];
-    if (residual) {
-      const float* pr = residual + ebase;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) res[r] = ((r & 3) + 8 * (r >> 2)) < lim ? pr[((r & 3) + 8 * (r >> 2)) * C] : 0.f;
     }
     // ---- dW[:, n0..n0+31] += (aux * gate)^T X over the wave's 32 rows (lane half h: rows 16h .. 16h+15)
     float gl[NT];
@@ -932,7 +955,8 @@ static void run_gemm_dual(const float* X, const float* W, const float* aux, cons
                           hipStream_t s) {
   constexpr int TR = 32 * (4 / (C / 32));
   int64_t ntiles = (M + TR - 1) / TR;
-  int grid = (int)(ntiles < 512 ? ntiles : 512);          // 256 CUs x 2 resident blocks
+  const int cap = 2 * big_grid_cus();                      // 2 resident blocks per CU
+  int grid = (int)(ntiles < cap ? ntiles : cap);
   hipLaunchKernelGGL((k_gemm_dual<C>), dim3(grid), dim3(256), 0, s, X, W, aux, gate, residual, Y, sl.at(dW), sl.at(db),
                      dot_out, M, rpi, sl.count(), sl.stride);
 }

@@ -17,7 +17,7 @@ struct Profiler {
   bool by_size = getenv("MVAE_PROF_SIZES") != nullptr;   // diagnostics: split every tag by log2(bytes)
   std::vector<std::string> tags;
   std::vector<ProfRec> recs;
-  std::vector<hipStream_t> streams;           // by_size mode: launch streams in order of first appearance
+  int cur_scale = -1;                         // set by the runtime around each pyramid scale's launches (diagnostics)
   int tag_id(const char* name) {
     for (size_t i = 0; i < tags.size(); ++i)
       if (tags[i] == name) return (int)i;
@@ -38,10 +38,7 @@ struct ProfScope {
       char buf[96];
       int lg = 0;
       while ((1ll << lg) < (long long)bytes) ++lg;
-      size_t si = 0;
-      while (si < p.streams.size() && p.streams[si] != stream) ++si;
-      if (si == p.streams.size()) p.streams.push_back(stream);
-      snprintf(buf, sizeof(buf), "%s#%dB/q%d", tag, lg, (int)si);
+      snprintf(buf, sizeof(buf), "%s#%dB/q%d", tag, lg, p.cur_scale);
       r.tag = p.tag_id(buf);
     } else {
       r.tag = p.tag_id(tag);

@@ -109,6 +109,7 @@ struct mvae_handle {
   // events); each ABI call is captured into a hipGraph per argument signature and replayed.
   // wgrad_streams: opt-in (MVAE_WGRAD_STREAMS=1).  Correct in eager mode, but the ~450 extra event calls per step
   // make the host the bottleneck there, and capturing that many cross-stream edges crashes hipGraph (ROCm 7.2).
+  bool merge_side = false;
   bool multi_stream = true, use_graphs = true, wgrad_streams = false;
   hipStream_t side[MVAE_MAX_LEVELS] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MVAE_MAX_LEVELS] = {};
@@ -613,16 +614,22 @@ void merge_forward(mvae_handle* h, int B, float* recon, hipStream_t s) {
 }
 
 // ---- fork / join of the per-scale chains over the side streams ------------------------------
+// the instrumented pass runs the scales one after another (isolated kernel durations) unless MVAE_PROF_MULTI is set
+static bool serial_scales(mvae_handle* h) {
+  static const bool prof_multi = getenv("MVAE_PROF_MULTI") != nullptr;
+  return !h->multi_stream || (profiler().on && !prof_multi);
+}
 hipStream_t scale_stream(mvae_handle* h, int scale, hipStream_t main) {
-  return (h->multi_stream && scale > 0 && !profiler().on) ? h->side[scale] : main;
+  if (serial_scales(h) || scale == 0) return main;
+  return h->side[h->merge_side ? 1 : scale];
 }
 void fork_scales(mvae_handle* h, hipStream_t main) {
-  if (!h->multi_stream || profiler().on) return;
+  if (serial_scales(h)) return;
   (void)hipEventRecord(h->ev_fork, main);
   for (int l = 1; l < h->cfg.levels; ++l) (void)hipStreamWaitEvent(h->side[l], h->ev_fork, 0);
 }
 void join_scales(mvae_handle* h, hipStream_t main) {
-  if (!h->multi_stream || profiler().on) return;
+  if (serial_scales(h)) return;
   for (int l = 1; l < h->cfg.levels; ++l) {
     (void)hipEventRecord(h->ev_join[l], h->side[l]);
     (void)hipStreamWaitEvent(main, h->ev_join[l], 0);
@@ -792,6 +799,7 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   if (const char* v = getenv("MVAE_GRAPHS")) h->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("MVAE_STREAMS")) h->multi_stream = atoi(v) != 0;
   if (const char* v = getenv("MVAE_WGRAD_STREAMS")) h->wgrad_streams = atoi(v) != 0;
+  if (const char* v = getenv("MVAE_MERGE_SIDE")) h->merge_side = atoi(v) != 0;   // all scales > 0 on ONE side stream
   if (h->wgrad_streams) h->use_graphs = false;
   // scale 0 (on the caller's stream) is the long pole of every step: the other scales only fill the gaps it leaves,
   // so their streams get the lowest priority
@@ -867,6 +875,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
     PreOp none{nullptr, nullptr, nullptr};
     for (int si = L - 1; si >= 0; --si) {
       hipStream_t ss = scale_stream(h, si, s);
+      profiler().cur_scale = si;
       Scale& sc = h->scales[si];
       ConvGeom g{};
       g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
@@ -942,6 +951,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
   hipStream_t s_main = s;
   for (int si = L - 1; si >= 0; --si) {
     hipStream_t s = scale_stream(h, si, s_main);
+    profiler().cur_scale = si;
     Scale& sc = h->scales[si];
     for (int k = 0; k < 4; ++k) { sc.scratch_used[k] = false; sc.buf_pending[k] = false; }
     const int64_t M = (int64_t)B * sc.H * sc.W;
@@ -1071,6 +1081,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     release(sc, d);
   }
   join_scales(h, s_main);
+  profiler().cur_scale = -1;
   if (h->gslots.n) launch_slot_sum(G, h->gslots.base, h->P, h->gslots.stride, h->gslots.n, s_main);
   };
   int rc = MVAE_OK;
