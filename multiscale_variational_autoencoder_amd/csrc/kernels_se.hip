@@ -23,24 +23,53 @@ constexpr int kSeRowsMax = 64;                       // rows per block: 16 (B <=
 __device__ __forceinline__ float se_hsig(float v) { return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f); }
 __device__ __forceinline__ float se_hsig_grad(float u) { return (u >= -2.5f && u <= 2.5f) ? 0.2f : 0.f; }
 
-// out[r][j] = bias[j] + sum_k sA[r][k] * W[k*C + j] for the block's rows; thread (j = t % C, rq = t / C) owns rows
-// rq, rq + G, ...  W is read straight from global (lanes -> consecutive j: coalesced, L2-resident).
+// Every global load of these kernels is issued up front as one unrolled batch (weights, per-block partials, the
+// block's rows): the kernels are chains of dependent memory round trips, so each trip saved is ~1 us of the ~5.
+//
+// wcol[k] = W[k*C + j]: the Dense weight column of thread j, one batch of C coalesced loads
+template <int C>
+__device__ __forceinline__ void se_load_wcol(const float* __restrict__ W, int j, float (&wcol)[C]) {
+#pragma unroll
+  for (int k = 0; k < C; ++k) wcol[k] = W[k * C + j];
+}
+// out[r][j] = bias[j] + sum_k sA[r][k] * wcol[k] for the block's rows; thread (j = t % C, rq = t / C) owns rows
+// rq, rq + G, ...
 template <int C, int RPT>
-__device__ __forceinline__ void se_fc_rows(const float* sA, const float* __restrict__ W, float bias, int j, int rq,
-                                           float (&acc)[RPT]) {
+__device__ __forceinline__ void se_fc_rows(const float* sA, const float (&wcol)[C], float bias, int rq, float (&acc)[RPT]) {
   constexpr int G = 256 / C;
 #pragma unroll
   for (int q = 0; q < RPT; ++q) acc[q] = bias;
-#pragma unroll 4
-  for (int k0 = 0; k0 < C; k0 += 4) {
-    float w[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = W[(k0 + e) * C + j];
+  for (int k0 = 0; k0 < C; k0 += 4) {
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
       const float4 a = *reinterpret_cast<const float4*>(&sA[(rq + q * G) * C + k0]);
-      acc[q] += a.x * w[0] + a.y * w[1] + a.z * w[2] + a.w * w[3];
+      acc[q] += a.x * wcol[k0] + a.y * wcol[k0 + 1] + a.z * wcol[k0 + 2] + a.w * wcol[k0 + 3];
     }
+  }
+}
+// W[C][C] -> sW with row pitch C + 1: the C*C/256 loads of a thread as one batch, then the LDS stores
+template <int C>
+__device__ __forceinline__ void se_stage_w(const float* __restrict__ W, float* sW) {
+  float wv[C * C / 256];
+#pragma unroll
+  for (int u = 0; u < C * C / 256; ++u) wv[u] = W[threadIdx.x + u * 256];
+#pragma unroll
+  for (int u = 0; u < C * C / 256; ++u) {
+    const int idx = threadIdx.x + u * 256;
+    sW[(idx / C) * (C + 1) + idx % C] = wv[u];
+  }
+}
+// the per-block partials part[i][which][j], i = rq, rq + G, ... (<= kMaxPart of them), as one batch of loads
+constexpr int kSeMaxBlocks = 64;
+template <int C>
+__device__ __forceinline__ void se_load_part(const float* __restrict__ part, int nblk, int which, int j, int rq,
+                                             float (&v)[kSeMaxBlocks / (256 / C)]) {
+  constexpr int G = 256 / C;
+#pragma unroll
+  for (int t = 0; t < kSeMaxBlocks / G; ++t) {
+    const int i = rq + t * G;
+    v[t] = part[((int64_t)(i < nblk ? i : 0) * 2 + which) * C + j];
   }
 }
 }  // namespace
@@ -56,6 +85,9 @@ __global__ void __launch_bounds__(256) k_se_fwd1(const float* __restrict__ gap, 
   __shared__ float smean[C];
   const int j = threadIdx.x % C, rq = threadIdx.x / C;
   const int r0 = blockIdx.x * RB, nrows = min(RB, B - r0);
+  float wcol[C];
+  se_load_wcol<C>(W0, j, wcol);
+  const float bias = b0[j];
   for (int idx = threadIdx.x; idx < ROWS * C / 4; idx += 256) {
     const int r = idx / (C / 4);
     float4 v = {0.f, 0.f, 0.f, 0.f};
@@ -64,7 +96,7 @@ __global__ void __launch_bounds__(256) k_se_fwd1(const float* __restrict__ gap, 
   }
   __syncthreads();
   float acc[RPT];
-  se_fc_rows<C, RPT>(sA, W0, b0[j], j, rq, acc);
+  se_fc_rows<C, RPT>(sA, wcol, bias, rq, acc);
   float sum = 0.f;
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
@@ -120,12 +152,26 @@ __global__ void __launch_bounds__(256) k_se_fwd2(const float* __restrict__ s0, c
   __shared__ float smean[C], sinv[C];
   const int j = threadIdx.x % C, rq = threadIdx.x / C;
   const int r0 = blockIdx.x * RB, nrows = min(RB, B - r0);
+  // all global loads first: weight column, this block's rows of s0, the per-block statistics
+  float wcol[C];
+  se_load_wcol<C>(W1, j, wcol);
+  const float bias = b1[j], gm = gamma[j], bt = beta[j];
+  float xs[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int r = rq + q * G;
+    xs[q] = s0[(int64_t)(r0 + (r < nrows ? r : 0)) * C + j];
+  }
   if (training) {
-    // mean = sum n_i mean_i / B ; M2 = sum (M2_i + n_i (mean_i - mean)^2)
+    // mean = sum n_i mean_i / B ; M2 = sum (M2_i + n_i (mean_i - mean)^2)   (pairwise merge of per-block statistics)
+    float pm[kSeMaxBlocks / G], p2[kSeMaxBlocks / G];
+    se_load_part<C>(part, nblk, 0, j, rq, pm);
+    se_load_part<C>(part, nblk, 1, j, rq, p2);
     float t = 0.f;
-    for (int i = rq; i < nblk; i += G) {
-      const float ni = (float)min(RB, B - i * RB);
-      t += ni * part[((int64_t)i * 2 + 0) * C + j];
+#pragma unroll
+    for (int u = 0; u < kSeMaxBlocks / G; ++u) {
+      const int i = rq + u * G;
+      if (i < nblk) t += (float)min(RB, B - i * RB) * pm[u];
     }
     red[rq][j] = t;
     __syncthreads();
@@ -138,10 +184,11 @@ __global__ void __launch_bounds__(256) k_se_fwd2(const float* __restrict__ s0, c
     __syncthreads();
     const float mu = smean[j];
     t = 0.f;
-    for (int i = rq; i < nblk; i += G) {
-      const float ni = (float)min(RB, B - i * RB);
-      const float d = part[((int64_t)i * 2 + 0) * C + j] - mu;
-      t += part[((int64_t)i * 2 + 1) * C + j] + ni * d * d;
+#pragma unroll
+    for (int u = 0; u < kSeMaxBlocks / G; ++u) {
+      const int i = rq + u * G;
+      const float d = pm[u] - mu;
+      if (i < nblk) t += p2[u] + (float)min(RB, B - i * RB) * d * d;
     }
     __syncthreads();
     red[rq][j] = t;
@@ -159,14 +206,14 @@ __global__ void __launch_bounds__(256) k_se_fwd2(const float* __restrict__ s0, c
     sinv[j] = rsqrtf(mov_var[j] + eps);
   }
   __syncthreads();
-  const float mu = smean[j], inv = sinv[j], gm = gamma[j], bt = beta[j];
+  const float mu = smean[j], inv = sinv[j];
   if (blockIdx.x == 0 && rq == 0) invstd[j] = inv;
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
     const int r = rq + q * G;
     float s1 = 0.f;
     if (r < nrows) {
-      const float xh = (s0[(int64_t)(r0 + r) * C + j] - mu) * inv;
+      const float xh = (xs[q] - mu) * inv;
       xhat[(int64_t)(r0 + r) * C + j] = xh;
       s1 = xh * gm + bt;
     }
@@ -174,7 +221,7 @@ __global__ void __launch_bounds__(256) k_se_fwd2(const float* __restrict__ s0, c
   }
   __syncthreads();
   float acc[RPT];
-  se_fc_rows<C, RPT>(sA, W1, b1[j], j, rq, acc);
+  se_fc_rows<C, RPT>(sA, wcol, bias, rq, acc);
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
     const int r = rq + q * G;
@@ -238,22 +285,22 @@ __global__ void __launch_bounds__(256) k_se_bwd1(const float* __restrict__ dg, c
   const int j = threadIdx.x % C, rq = threadIdx.x / C;
   const int r0 = blockIdx.x * RB, nrows = min(RB, B - r0);
   const float gm = gamma[j], bt = beta[j];
-  float xh[RPT];
+  float xh[RPT], rdg[RPT], rul[RPT];                  // the block's rows, raw (clamped), one batch of loads
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
     const int r = rq + q * G;
-    float du = 0.f, s1 = 0.f;
-    xh[q] = 0.f;
-    if (r < nrows) {
-      const int64_t o = (int64_t)(r0 + r) * C + j;
-      du = dg[o] * se_hsig_grad(ulin[o]);
-      xh[q] = xhat[o];
-      s1 = xh[q] * gm + bt;
-    }
-    sV[r * C + j] = du;
-    sX[r * C + j] = s1;
+    const int64_t o = (int64_t)(r0 + (r < nrows ? r : 0)) * C + j;
+    rdg[q] = dg[o]; rul[q] = ulin[o]; xh[q] = xhat[o];
   }
-  for (int idx = threadIdx.x; idx < C * C; idx += 256) sW[(idx / C) * (C + 1) + idx % C] = W1[idx];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int r = rq + q * G;
+    const bool ok = r < nrows;
+    xh[q] = ok ? xh[q] : 0.f;
+    sV[r * C + j] = ok ? rdg[q] * se_hsig_grad(rul[q]) : 0.f;
+    sX[r * C + j] = ok ? xh[q] * gm + bt : 0.f;
+  }
+  se_stage_w<C>(W1, sW);
   __syncthreads();
   const int64_t slot = (int64_t)(blockIdx.x % nslots) * slot_stride;
   float dx[RPT];
@@ -297,14 +344,26 @@ __global__ void __launch_bounds__(256) k_se_bwd2(const float* __restrict__ ds1, 
   __shared__ float stot[2][C];
   const int j = threadIdx.x % C, rq = threadIdx.x / C;
   const int r0 = blockIdx.x * RB, nrows = min(RB, B - r0);
+  float rds[RPT], rxh[RPT], rs0[RPT], rgp[RPT];                // the block's rows, raw, issued before any barrier
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int r = rq + q * G;
+    const int64_t o = (int64_t)(r0 + (r < nrows ? r : 0)) * C + j;
+    rds[q] = ds1[o]; rxh[q] = xhat[o]; rs0[q] = s0[o]; rgp[q] = gap[o];
+  }
   float p1 = 0.f, p2 = 0.f;
-  for (int i = rq; i < nblk; i += G) {
-    p1 += part[((int64_t)i * 2 + 0) * C + j];
-    p2 += part[((int64_t)i * 2 + 1) * C + j];
+  {
+    float v1[kSeMaxBlocks / G], v2[kSeMaxBlocks / G];
+    se_load_part<C>(part, nblk, 0, j, rq, v1);
+    se_load_part<C>(part, nblk, 1, j, rq, v2);
+#pragma unroll
+    for (int u = 0; u < kSeMaxBlocks / G; ++u) {
+      if (rq + u * G < nblk) { p1 += v1[u]; p2 += v2[u]; }
+    }
   }
   red[0][rq][j] = p1;
   red[1][rq][j] = p2;
-  for (int idx = threadIdx.x; idx < C * C; idx += 256) sW[(idx / C) * (C + 1) + idx % C] = W0[idx];
+  se_stage_w<C>(W0, sW);
   __syncthreads();
   if (rq < 2) {
     float t = 0.f;
@@ -324,10 +383,9 @@ __global__ void __launch_bounds__(256) k_se_bwd2(const float* __restrict__ ds1, 
     const int r = rq + q * G;
     float dv = 0.f, gp = 0.f;
     if (r < nrows) {
-      const int64_t o = (int64_t)(r0 + r) * C + j;
-      const float v = gi * (ds1[o] - md - xhat[o] * mdx);
-      dv = s0[o] > 0.f ? v : 0.f;
-      gp = gap[o];
+      const float v = gi * (rds[q] - md - rxh[q] * mdx);
+      dv = rs0[q] > 0.f ? v : 0.f;
+      gp = rgp[q];
     }
     sV[r * C + j] = dv;
     sX[r * C + j] = gp;
