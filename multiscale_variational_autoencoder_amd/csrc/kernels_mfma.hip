@@ -90,9 +90,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
 
   // Prefetch = RAW loads only, all issued back to back (pre-ops are applied when the tile is written to LDS, a whole
   // MFMA phase later): anything computed between the loads makes hipcc wait for each load before issuing the next.
-  // The squeeze-excite gate is constant over a tile (launcher: rows_per_image % 32 == 0): one 16-byte load per tile.
+  // The squeeze-excite gate is constant over each 16-row half of a tile (launcher: rows_per_image % 16 == 0, so 4x4
+  // feature maps qualify): two 16-byte loads per tile.
   f32x4 stage[LD];
-  f32x4 gstage = {1.f, 1.f, 1.f, 1.f};
+  f32x4 gstage = {1.f, 1.f, 1.f, 1.f}, gstage1 = {1.f, 1.f, 1.f, 1.f};
   const uint32_t rpi32 = (uint32_t)rows_per_image;
   auto load_tile = [&](int64_t tile) {
     const int64_t row0 = tile * 128 + wave * 32;
@@ -102,8 +103,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
       stage[j] = row < M ? X4[row * C4 + lc4] : z;
     }
-    if (pre.gate && row0 < M)
+    if (pre.gate && row0 < M) {
       gstage = reinterpret_cast<const f32x4*>(pre.gate)[(int64_t)((uint32_t)row0 / rpi32) * C4 + lc4];
+      const uint32_t r1 = (uint32_t)(row0 + 16 < M ? row0 + 16 : row0);
+      gstage1 = reinterpret_cast<const f32x4*>(pre.gate)[(int64_t)(r1 / rpi32) * C4 + lc4];
+    }
   };
 
   int64_t tile = blockIdx.x;
@@ -115,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
     for (int j = 0; j < LD; ++j) {
       f32x4 v = stage[j];
       if (pre.scale) v = v * psc + psh;
-      if (pre.gate) v = v * gstage;
+      if (pre.gate) v = v * (j * RPL >= 16 ? gstage1 : gstage);        // RPL divides 16: rows j*RPL+lr < 16 <=> j*RPL < 16
       if (row0 + j * RPL + lr >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(&sT[(j * RPL + lr) * TS + lc4 * 4]) = v;
     }
@@ -201,7 +205,8 @@ bool launch_conv1x1_mfma(bool transposed, const float* in, const float* w, const
                          float* out, const ConvGeom& g, PreOp pre, int act, const float* dot_src, float* dot_out,
                          hipStream_t s) {
   if (g.KH != 1 || g.KW != 1 || g.SH != 1 || g.SW != 1) return false;
-  if ((dot_src || pre.gate) && (((int64_t)g.IH * g.IW) % 32) != 0) return false;
+  if (dot_src && (((int64_t)g.IH * g.IW) % 32) != 0) return false;
+  if (pre.gate && (((int64_t)g.IH * g.IW) % 16) != 0) return false;
   const int K = transposed ? g.CO : g.CI, N = transposed ? g.CI : g.CO;
   const int64_t M = (int64_t)g.B * g.IH * g.IW, rpi = (int64_t)g.IH * g.IW;
 #define MVAE_GR(KK, NN)                                                                                   \
@@ -878,10 +883,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[q * 4 + e], acc, 0, 0, 0);
     }
     // ---- dW[:, n0..n0+31] += (aux * gate)^T X over the wave's 32 rows (lane half h: rows 16h .. 16h+15)
+    // lane half h reads fragment rows 16h .. 16h+15 of the wave's 32: one image per half when rows_per_image % 16 == 0
+    const int64_t rowh = row0 + 16 * h < M ? row0 + 16 * h : row0;
     float gl[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
-      gl[kt] = (gate && row0 < M) ? gate[(row0 / rows_per_image) * C + kt * 32 + i] : 1.0f;
+      gl[kt] = (gate && row0 < M) ? gate[(rowh / rows_per_image) * C + kt * 32 + i] : 1.0f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       float av[8][NT], bv[8];
@@ -902,7 +909,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
       }
     }
     // ---- epilogue straight from the accumulator layout
-    float dsum = 0.f;
+    float dsum[2] = {0.f, 0.f};                            // accumulator rows < 16 / >= 16: one image each
     float* py = Y + ebase;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -911,12 +918,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
       if (residual) v += res[r];
       if (rc < lim) {
         py[rc * C] = v;
-        if (dot_out) dsum += v * sA[SWZ1(rw * 32 + rc + 4 * h, n0 + i)];
+        if (dot_out) dsum[r >> 3] += v * sA[SWZ1(rw * 32 + rc + 4 * h, n0 + i)];
       }
     }
     if (dot_out) {
-      dsum += __shfl_xor(dsum, 32, 64);
-      if (h == 0 && row0 < M) atomicAdd(dot_out + (row0 / rows_per_image) * C + n0 + i, dsum);
+      dsum[0] += __shfl_xor(dsum[0], 32, 64);
+      dsum[1] += __shfl_xor(dsum[1], 32, 64);
+      if (h == 0 && row0 < M) atomicAdd(dot_out + (row0 / rows_per_image) * C + n0 + i, dsum[0]);
+      if (h == 1 && row0 + 16 < M) atomicAdd(dot_out + ((row0 + 16) / rows_per_image) * C + n0 + i, dsum[1]);
     }
   }
   // ---- reduce the row groups' dW slabs through LDS, then one coalesced float-atomic set per block
@@ -965,7 +974,7 @@ static void run_gemm_dual(const float* X, const float* W, const float* aux, cons
 bool launch_gemm_dual_mfma(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
                            float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
                            GradSlots sl, hipStream_t s) {
-  if ((gate || dot_out) && (rows_per_image % 32) != 0) return false;
+  if ((gate || dot_out) && (rows_per_image % 16) != 0) return false;
   if (C == 64) { run_gemm_dual<64>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, sl, s); return true; }
   if (C == 32) { run_gemm_dual<32>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, sl, s); return true; }
   return false;
