@@ -59,7 +59,6 @@ struct GradSlots {
   float* at(float* g) const { return (n && g) ? base + (g - gbase) : g; }
   int count() const { return n ? n : 1; }
 };
-void launch_slot_sum(float* g, const float* slots, int64_t elems, int64_t stride, int n, hipStream_t s);
 bool launch_gemm_dual_mfma(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
                            float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
                            GradSlots slots, hipStream_t s);
@@ -156,6 +155,10 @@ void launch_metrics(const float* losses, int ncol, int B, float* metrics, hipStr
 
 // ---- optimiser (multiscale_vae.py:497-499) ----
 struct ChunkDesc { int64_t offset; int32_t len; int32_t tensor; int32_t reg; int32_t pad; };
+// zero / fold the gradient-slot copies of the listed (single-chunk) tensors
+void launch_slot_zero(const ChunkDesc* chunks, int nchunks, float* slots, int64_t stride, int n, hipStream_t s);
+void launch_slot_sum(const ChunkDesc* chunks, int nchunks, float* g, const float* slots, int64_t stride, int n,
+                     hipStream_t s);
 // g = g*grad_scale + reg'(w) ; norms[tensor] += sum g^2
 void launch_opt_prepare(const float* w, float* g, const ChunkDesc* chunks, int nchunks, float* norms,
                         float grad_scale, hipStream_t s);

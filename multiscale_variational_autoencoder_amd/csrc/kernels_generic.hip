@@ -1181,25 +1181,46 @@ void launch_state_update(float* state, const float* stats, const StateDesc* desc
   hipLaunchKernelGGL(k_state_update, dim3(ndesc), dim3(64), 0, s, state, stats, descs, stat_scale, B);
 }
 
-// g[i] += sum over the n gradient-slot copies (kernels.h: GradSlots); elems and stride are multiples of 4
-__global__ void __launch_bounds__(256) k_slot_sum(float* __restrict__ g, const float* __restrict__ slots, int64_t n4,
-                                                  int64_t stride4, int n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  float4 a = reinterpret_cast<float4*>(g)[i];
-  const float4* sp = reinterpret_cast<const float4*>(slots) + i;
+// Gradient-slot copies (kernels.h: GradSlots) are laid out like the gradient arena, but only tensors of at most one
+// chunk ever receive slot atomics: zero / fold just those chunks (a table of (offset, len)), not n x P floats.
+__global__ void __launch_bounds__(256) k_slot_zero(const ChunkDesc* __restrict__ chunks, float* __restrict__ slots,
+                                                   int64_t stride) {
+  const ChunkDesc cd = chunks[blockIdx.x];
+  float* p = slots + (int64_t)blockIdx.y * stride + cd.offset;          // tensor offsets are 256-byte aligned
+  const int n4 = cd.len / 4;
+  for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(p)[i] = float4{0.f, 0.f, 0.f, 0.f};
+  for (int i = n4 * 4 + threadIdx.x; i < cd.len; i += 256) p[i] = 0.f;
+}
+__global__ void __launch_bounds__(256) k_slot_sum(const ChunkDesc* __restrict__ chunks, float* __restrict__ g,
+                                                  const float* __restrict__ slots, int64_t stride, int n) {
+  const ChunkDesc cd = chunks[blockIdx.x];
+  float* gp = g + cd.offset;
+  const float* sp = slots + cd.offset;
+  const int n4 = cd.len / 4;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    float4 a = reinterpret_cast<float4*>(gp)[i];
 #pragma unroll 8
-  for (int k = 0; k < n; ++k) {
-    float4 v = sp[k * stride4];
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    for (int k = 0; k < n; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(sp + (int64_t)k * stride)[i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(gp)[i] = a;
   }
-  reinterpret_cast<float4*>(g)[i] = a;
+  for (int i = n4 * 4 + threadIdx.x; i < cd.len; i += 256) {
+    float a = gp[i];
+    for (int k = 0; k < n; ++k) a += sp[(int64_t)k * stride + i];
+    gp[i] = a;
+  }
 }
 
-void launch_slot_sum(float* g, const float* slots, int64_t elems, int64_t stride, int n, hipStream_t s) {
-  ProfScope ps("slot_sum", 4.0 * elems * (n + 2), (double)elems * n, s);
-  const int64_t n4 = elems / 4;
-  hipLaunchKernelGGL(k_slot_sum, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g, slots, n4, stride / 4, n);
+void launch_slot_zero(const ChunkDesc* chunks, int nchunks, float* slots, int64_t stride, int n, hipStream_t s) {
+  ProfScope ps("slot_sum", 0.0, 0.0, s);
+  hipLaunchKernelGGL(k_slot_zero, dim3(nchunks, n), dim3(256), 0, s, chunks, slots, stride);
+}
+void launch_slot_sum(const ChunkDesc* chunks, int nchunks, float* g, const float* slots, int64_t stride, int n,
+                     hipStream_t s) {
+  ProfScope ps("slot_sum", 0.0, 0.0, s);
+  hipLaunchKernelGGL(k_slot_sum, dim3(nchunks), dim3(256), 0, s, chunks, g, slots, stride, n);
 }
 
 }  // namespace mvae

@@ -92,6 +92,9 @@ struct mvae_handle {
   int64_t P = 0, S = 0, Z = 0, MET = 0;
   int64_t ws_floats = 0;
   std::vector<ChunkDesc> chunks;
+  std::vector<ChunkDesc> slot_chunks;       // tensors of at most one chunk: the only ones that receive slot atomics
+  ChunkDesc* d_slot_chunks = nullptr;
+  int64_t off_slot_chunks = 0;
   std::vector<StateDesc> sdescs;
   // workspace offsets of the fixed tables / buffers
   int64_t off_chunks = 0, off_sdescs = 0, off_norms = 0, off_slots = 0;
@@ -349,6 +352,8 @@ int build_plan(mvae_handle* h) {
       h->chunks.push_back(cd);
     }
   }
+  for (const ChunkDesc& cd : h->chunks)
+    if (h->params[cd.tensor].elems <= kChunk) h->slot_chunks.push_back(cd);
   for (const StateInfo& s : h->states) {
     StateDesc sd;
     sd.offset = s.offset; sd.len = (int32_t)s.elems; sd.momentum = s.momentum;
@@ -357,6 +362,7 @@ int build_plan(mvae_handle* h) {
     h->sdescs.push_back(sd);
   }
   h->off_chunks = b.ws_alloc((int64_t)(h->chunks.size() * sizeof(ChunkDesc) + 3) / 4);
+  h->off_slot_chunks = b.ws_alloc((int64_t)(h->slot_chunks.size() * sizeof(ChunkDesc) + 3) / 4);
   h->off_sdescs = b.ws_alloc((int64_t)(h->sdescs.size() * sizeof(StateDesc) + 3) / 4);
   h->off_norms = b.ws_alloc((int64_t)h->params.size());
   h->off_seed = b.ws_alloc(kAlign);
@@ -393,6 +399,7 @@ void rebase_all(mvae_handle* h) {
   rb(h->eps_buf); rb(h->noise_buf); rb(h->keep_buf); rb(h->recon); rb(h->losses); rb(h->sgn); rb(h->reg_tmp);
   h->d_chunks = reinterpret_cast<ChunkDesc*>(base + h->off_chunks);
   h->d_sdescs = reinterpret_cast<StateDesc*>(base + h->off_sdescs);
+  h->d_slot_chunks = reinterpret_cast<ChunkDesc*>(base + h->off_slot_chunks);
   h->d_norms = base + h->off_norms;
   h->gslots.base = base + h->off_slots;
   h->gslots.stride = h->P;
@@ -785,6 +792,8 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   h->gslots.gbase = h->dr;
   if (const char* v = getenv("MVAE_GRAD_SLOTS")) h->gslots.n = atoi(v) > 0 && atoi(v) <= kGradSlots ? atoi(v) : 0;
   e = hipMemcpy(h->d_chunks, h->chunks.data(), h->chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !h->slot_chunks.empty())
+    e = hipMemcpy(h->d_slot_chunks, h->slot_chunks.data(), h->slot_chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
   if (e == hipSuccess && !h->sdescs.empty())
     e = hipMemcpy(h->d_sdescs, h->sdescs.data(), h->sdescs.size() * sizeof(StateDesc), hipMemcpyHostToDevice);
   if (e != hipSuccess) return fail(h, MVAE_E_HIP, "table upload: %s", hipGetErrorString(e));
@@ -944,7 +953,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
   PreOp none{nullptr, nullptr, nullptr};
   h->ev_next = 0;
   launch_zero(G, (int64_t)(h->P), s);
-  if (h->gslots.n) launch_zero(h->gslots.base, (int64_t)h->gslots.n * h->P, s);
+  if (h->gslots.n) launch_slot_zero(h->d_slot_chunks, (int)h->slot_chunks.size(), h->gslots.base, h->gslots.stride, h->gslots.n, s);
   // ---- loss -> clip/denormalise -> merge
   launch_loss_bwd(h->last_x, h->recon, h->scales[0].merged, h->sgn, h->scales[0].dy, B, c.input_h, c.input_w, C,
                   c.min_value, c.max_value, r_factor / (float)B, s);
@@ -1086,7 +1095,8 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
   }
   join_scales(h, s_main);
   profiler().cur_scale = -1;
-  if (h->gslots.n) launch_slot_sum(G, h->gslots.base, h->P, h->gslots.stride, h->gslots.n, s_main);
+  if (h->gslots.n)
+    launch_slot_sum(h->d_slot_chunks, (int)h->slot_chunks.size(), G, h->gslots.base, h->gslots.stride, h->gslots.n, s_main);
   };
   int rc = MVAE_OK;
   if (h->last_x == h->xin && h->last_eps == h->eps_buf)
