@@ -83,6 +83,11 @@ def load_library(path=None):
         raise RuntimeError(
             "libmvae_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP path." % p)
+    # The engine shares device memory, streams and RCCL with PyTorch, so both must run on ONE HIP runtime: torch is
+    # imported first and libmvae_hip.so then binds to the libamdhip64 torch has already loaded.  Loaded the other way
+    # round the process ends up with two runtimes and the second one finds no device (hipSetDevice: "no ROCm-capable
+    # device is detected").
+    import torch  # noqa: F401
     lib = C.CDLL(p)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError if the library does not export it

@@ -253,7 +253,6 @@ class MultiscaleVAE:
         if dist.is_available() and dist.is_initialized():
             world, rank = dist.get_world_size(), dist.get_rank()
         n = len(x)
-        rng = np.random.default_rng(self._seed + 1)
         hist = History()
         c = self._compiled
         for cb in callbacks:
@@ -263,7 +262,8 @@ class MultiscaleVAE:
             for cb in callbacks:
                 if hasattr(cb, "on_epoch_begin"):
                     cb.on_epoch_begin(epoch, {})
-            order = rng.permutation(n) if shuffle else np.arange(n)
+            # the shuffle of epoch e depends on (seed, e) only: a run resumed with initial_epoch=e sees the same batches
+            order = np.random.default_rng([self._seed + 1, epoch]).permutation(n) if shuffle else np.arange(n)
             t0 = time.time()
             acc, seen, eng = None, 0, None
             for bi, start in enumerate(range(0, n, batch_size)):
@@ -344,6 +344,7 @@ class MultiscaleVAE:
         blob.update({"s/" + k: v for k, v in self._state.items()})
         if self._accum is not None:
             blob.update({"a/" + k: v for k, v in self._accum.items()})
+        blob["meta/step"] = np.asarray(self._step, dtype=np.int64)      # position of the device RNG stream
         np.savez(filename, **blob)
 
     def load_weights(self, filename):
@@ -356,6 +357,8 @@ class MultiscaleVAE:
             self._state = OrderedDict((k, f["s/" + k]) for k in self._engine.state_table)
             if all(("a/" + k) in f for k in self._engine.param_table):
                 self._accum = OrderedDict((k, f["a/" + k]) for k in self._engine.param_table)
+            if "meta/step" in f:
+                self._step = int(f["meta/step"])
         if self._engine.bound:
             self._engine.set_params(self._weights)
             self._engine.set_state(self._state)
