@@ -311,14 +311,19 @@ class MultiscaleVAE:
               step_size=1,
               lr_decay=1,
               save_checkpoint_weights=False):
-        """multiscale_vae.py:508-557.  The reference also installs SaveIntermediateResultsCallback, which cannot
-        run even there (mvae/callbacks.py:10,77-78); image dumps are outside this build's hot path."""
+        """multiscale_vae.py:508-557: step-decay LR schedule, the intermediate-results image callback on
+        x_train[0:16] (callbacks.py), optional per-epoch checkpoints, then fit(x, x, shuffle=True).
+        `run_folder=None` (an extension) trains without touching the file system."""
         lr_schedule = _schedule.step_decay_schedule(
             initial_lr=self._learning_rate,
             decay_factor=lr_decay,
             step_size=step_size)
         callbacks_fns = [lr_schedule]
         if run_folder is not None:
+            from .callbacks import SaveIntermediateResultsCallback
+            os.makedirs(run_folder, exist_ok=True)
+            callbacks_fns.append(SaveIntermediateResultsCallback(
+                run_folder, print_every_n_batches, initial_epoch, np.asarray(x_train[0:16], np.float32), self))
             weights_path = os.path.join(run_folder, "weights")
             os.makedirs(weights_path, exist_ok=True)
             if save_checkpoint_weights:

@@ -41,6 +41,11 @@ def test_train_predict_encode_decode(tmp_path):
     assert hist.history["loss"][-1] < hist.history["loss"][0]              # it learns
     assert v.learning_rate == pytest.approx(0.01 * 0.5)                      # schedule.py:17-19 at epoch 3: floor(3/2)=1
     assert len(glob.glob(os.path.join(str(tmp_path), "weights", "weights-*.npz"))) == 4
+    # the intermediate-results callback (mvae/callbacks.py:66-135): every 100 batches -> batch 0 of each epoch here
+    for prefix in ("img", "samples", "interpolations"):
+        files = sorted(glob.glob(os.path.join(str(tmp_path), "images", prefix + "_*.png")))
+        assert [os.path.basename(f) for f in files] == ["%s_%03d_0.png" % (prefix, e) for e in (1, 2, 3, 4)], files
+        assert open(files[0], "rb").read(8) == b"\x89PNG\r\n\x1a\n"
     recon = v.model_trainable.predict(x[:10], batch_size=4)                  # last partial batch of 2
     assert recon.shape == (10, 16, 16, 3) and recon.dtype == np.float32
     assert recon.min() >= 0.0 and recon.max() <= 255.0                       # denormalize clips (multiscale_vae.py:86-94)

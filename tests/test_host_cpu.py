@@ -109,3 +109,34 @@ def test_weights_roundtrip_on_host(hip_lib, tmp_path):
     v2.load_weights(path)
     assert all(np.array_equal(v2._weights[k], v._weights[k]) for k in v._weights)
     v2.load_weights(str(tmp_path / "missing.h5"))                           # reference load_weights is a no-op stub
+
+
+def test_collage_resize_and_png_writer(tmp_path):
+    """callbacks.py helpers (the reference's callback needs a `collage` it never defines, mvae/callbacks.py:10,56)."""
+    import struct
+    import zlib
+    from multiscale_variational_autoencoder_amd.callbacks import collage, resize_nearest, save_png
+    x = np.arange(5 * 2 * 3 * 3, dtype=np.float32).reshape(5, 2, 3, 3)
+    c = collage(x)                                         # 5 images -> 3 x 2 grid
+    assert c.shape == (2 * 2, 3 * 3, 3)
+    assert np.array_equal(c[0:2, 3:6], x[1]) and np.array_equal(c[2:4, 0:3], x[3]) and np.all(c[2:4, 6:9] == 0)
+    assert collage(x[..., :1]).shape == (4, 9)             # single channel -> 2-D
+    r = resize_nearest(np.array([[0.0, 1.0], [2.0, 3.0]]), (4, 6))
+    assert r.shape == (4, 6) and np.array_equal(r[0], [0, 0, 0, 1, 1, 1]) and np.array_equal(r[:, 0], [0, 0, 2, 2])
+    path = str(tmp_path / "t.png")
+    img = np.linspace(0, 1, 4 * 5 * 3).reshape(4, 5, 3)
+    save_png(path, img)
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    w, h, depth, ctype = struct.unpack(">IIBB", raw[16:26])
+    assert (w, h, depth, ctype) == (5, 4, 8, 2)
+    n = struct.unpack(">I", raw[33:37])[0]
+    assert raw[37:41] == b"IDAT"
+    rows = zlib.decompress(raw[41:41 + n])
+    assert len(rows) == 4 * (1 + 5 * 3) and rows[0] == 0
+    assert np.array_equal(np.frombuffer(rows, np.uint8).reshape(4, 16)[:, 1:].reshape(4, 5, 3), np.rint(img * 255).astype(np.uint8))
+    try:
+        from PIL import Image
+        assert np.array_equal(np.asarray(Image.open(path)), np.rint(img * 255).astype(np.uint8))
+    except ImportError:
+        pass
