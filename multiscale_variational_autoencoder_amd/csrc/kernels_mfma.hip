@@ -48,7 +48,14 @@ __device__ __forceinline__ float act_apply_m(float v, int act) {
 //   WT = true : Wm[k][n] = W[n*K + k]   (its backward-data / Conv2DTranspose forward: kernel [1,1,CI=N,CO=K])
 // block = 4 waves; wave w owns rows [tile*128 + 32w, +32).  Persistent over tiles.
 // =================================================================================================
-template <int K, int N, bool WT>
+// FAST = (M % 128 == 0 and no fused dot): the tile loop is then straight-line code -- no row guards, every load
+// unconditional (clamped / dummy sources + selects), no conditional VMEM operation -- so hipcc can COUNT the outstanding
+// memory operations and waits for the prefetched tile with s_waitcnt vmcnt(N > 0).  With any branch around a load,
+// store or atomic it falls back to vmcnt(0) at the top of the loop, i.e. every tile also waited for the previous
+// tile's STORES to be acknowledged (stores share the in-order vmcnt counter on gfx9).
+// D2 = FAST and no residual: two tiles of prefetch (a residual launch already keeps two streams in flight, and its
+// registers do not leave room for a second tile buffer)
+template <int K, int N, bool WT, bool FAST, bool D2>
 __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ X, const float* __restrict__ W,
                                                    const float* __restrict__ bias, const float* __restrict__ residual,
                                                    float* __restrict__ Y, int64_t M, int64_t rows_per_image, PreOp pre,
@@ -92,46 +99,74 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
   // MFMA phase later): anything computed between the loads makes hipcc wait for each load before issuing the next.
   // The squeeze-excite gate is constant over each 16-row half of a tile (launcher: rows_per_image % 16 == 0, so 4x4
   // feature maps qualify): two 16-byte loads per tile.
-  f32x4 stage[LD];
-  f32x4 gstage = {1.f, 1.f, 1.f, 1.f}, gstage1 = {1.f, 1.f, 1.f, 1.f};
+  struct Stage { f32x4 st[LD]; f32x4 g0, g1; };
+  // FAST runs TWO tiles of prefetch ahead (buffers A and B alternate): with one tile (8 KB per wave, 64 KB per CU) the
+  // plain conv0 launch (one input stream) sat at 3.4 TB/s while conv2 (input + residual in flight) reached 5 TB/s --
+  // the kernel is limited by bytes in flight, not by MFMA or LDS work.
+  Stage A, Bq;
+  A.g0 = A.g1 = Bq.g0 = Bq.g1 = f32x4{1.f, 1.f, 1.f, 1.f};
   const uint32_t rpi32 = (uint32_t)rows_per_image;
-  auto load_tile = [&](int64_t tile) {
+  const f32x4* G4 = reinterpret_cast<const f32x4*>(pre.gate ? pre.gate : X);   // dummy source keeps the load unconditional
+  const f32x4* RS4 = residual ? R4 : reinterpret_cast<const f32x4*>(Y);        // likewise ([M,N] like the residual)
+  auto load_tile = [&](int64_t tile, Stage& S) {
     const int64_t row0 = tile * 128 + wave * 32;
+    if constexpr (FAST) {
 #pragma unroll
-    for (int j = 0; j < LD; ++j) {
-      int64_t row = row0 + j * RPL + lr;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      stage[j] = row < M ? X4[row * C4 + lc4] : z;
-    }
-    if (pre.gate && row0 < M) {
-      gstage = reinterpret_cast<const f32x4*>(pre.gate)[(int64_t)((uint32_t)row0 / rpi32) * C4 + lc4];
-      const uint32_t r1 = (uint32_t)(row0 + 16 < M ? row0 + 16 : row0);
-      gstage1 = reinterpret_cast<const f32x4*>(pre.gate)[(int64_t)(r1 / rpi32) * C4 + lc4];
+      for (int j = 0; j < LD; ++j) S.st[j] = X4[(row0 + j * RPL + lr) * C4 + lc4];
+      const uint32_t b0 = pre.gate ? (uint32_t)row0 / rpi32 : 0u, b1 = pre.gate ? (uint32_t)(row0 + 16) / rpi32 : 0u;
+      S.g0 = G4[(int64_t)b0 * C4 + lc4];
+      S.g1 = G4[(int64_t)b1 * C4 + lc4];
+    } else {
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+        int64_t row = row0 + j * RPL + lr;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        S.st[j] = row < M ? X4[row * C4 + lc4] : z;
+      }
+      if (pre.gate && row0 < M) {
+        S.g0 = reinterpret_cast<const f32x4*>(pre.gate)[(int64_t)((uint32_t)row0 / rpi32) * C4 + lc4];
+        const uint32_t r1 = (uint32_t)(row0 + 16 < M ? row0 + 16 : row0);
+        S.g1 = reinterpret_cast<const f32x4*>(pre.gate)[(int64_t)(r1 / rpi32) * C4 + lc4];
+      }
     }
   };
 
   int64_t tile = blockIdx.x;
-  if (tile < ntiles) load_tile(tile);
-  for (; tile < ntiles; tile += gridDim.x) {            // everything below is wave-private: no block barrier
+  const int64_t g1 = gridDim.x, g2 = 2 * (int64_t)gridDim.x;
+  if (tile < ntiles) {
+    load_tile(tile, A);
+    if constexpr (D2) load_tile(tile + g1 < ntiles ? tile + g1 : tile, Bq);
+  }
+  // S holds this tile (fetched two iterations ago in FAST mode); it is refilled for tile + ahead once it is in LDS
+  auto body = [&](int64_t tile, Stage& S, int64_t ahead) {    // everything below is wave-private: no block barrier
     const int64_t row0 = tile * 128 + wave * 32;
     WAVE_LDS_SYNC();     // the previous tile's C read-back is done
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
-      f32x4 v = stage[j];
+      f32x4 v = S.st[j];
       if (pre.scale) v = v * psc + psh;
-      if (pre.gate) v = v * (j * RPL >= 16 ? gstage1 : gstage);        // RPL divides 16: rows j*RPL+lr < 16 <=> j*RPL < 16
-      if (row0 + j * RPL + lr >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pre.gate) v = v * (j * RPL >= 16 ? S.g1 : S.g0);             // RPL divides 16: rows j*RPL+lr < 16 <=> j*RPL < 16
+      if (!FAST && row0 + j * RPL + lr >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(&sT[(j * RPL + lr) * TS + lc4 * 4]) = v;
     }
     WAVE_LDS_SYNC();
-    if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);    // prefetch under the MFMAs
     f32x4 res[ST];
-    if (residual) {
+    if constexpr (FAST) {
+      // prefetch under the MFMAs; past the last tile the current one is fetched again (never used)
+      load_tile(tile + ahead < ntiles ? tile + ahead : tile, S);
+      if constexpr (!D2) {
 #pragma unroll
-      for (int j = 0; j < ST; ++j) {
-        int64_t row = row0 + j * RPS + sr;
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        res[j] = row < M ? R4[row * N4 + sc4] : z;
+        for (int j = 0; j < ST; ++j) res[j] = RS4[(row0 + j * RPS + sr) * N4 + sc4];
+      }
+    } else {
+      if (tile + ahead < ntiles) load_tile(tile + ahead, S);
+      if (residual) {
+#pragma unroll
+        for (int j = 0; j < ST; ++j) {
+          int64_t row = row0 + j * RPS + sr;
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          res[j] = row < M ? R4[row * N4 + sc4] : z;
+        }
       }
     }
     f32x16 acc[NT];
@@ -139,17 +174,24 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-    f32x4 afr[KH / 4];
+    // fragments in two batches (KH/8 float4 each): all reads of a batch in flight ahead of its MFMAs (progressive
+    // lgkmcnt), half the registers of a single batch
+    constexpr int QH = KH / 8 > 0 ? KH / 8 : 1, NB = (KH / 4) / QH;
 #pragma unroll
-    for (int q = 0; q < KH / 4; ++q) afr[q] = *reinterpret_cast<const f32x4*>(&sT[i * TS + h * KH + q * 4]);
-    __builtin_amdgcn_sched_barrier(0);   // keep all fragment reads in flight ahead of the MFMAs (progressive lgkmcnt)
+    for (int bq = 0; bq < NB; ++bq) {
+      f32x4 afr[QH];
 #pragma unroll
-    for (int q = 0; q < KH / 4; ++q)
+      for (int q = 0; q < QH; ++q)
+        afr[q] = *reinterpret_cast<const f32x4*>(&sT[i * TS + h * KH + (bq * QH + q) * 4]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int q = 0; q < QH; ++q)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[q * 4 + e][nt], acc[nt], 0, 0, 0);
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[(bq * QH + q) * 4 + e][nt], acc[nt], 0, 0, 0);
+    }
     WAVE_LDS_SYNC();     // every lane's A fragments are consumed: the tile buffer becomes the C tile
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -166,13 +208,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_apply_m(v[e], act);
       }
-      if (residual) v = v + res[j];
-      if (row < M) {
+      if constexpr (!D2) {
+        if (residual) v = v + res[j];
+      }
+      if constexpr (FAST) {
+        Y4[row * N4 + sc4] = v;
+      } else if (row < M) {
         Y4[row * N4 + sc4] = v;
         if (dot_src) dsum += v * D4[row * N4 + sc4];
       }
     }
-    if (dot_src) {
+    if (!FAST && dot_src) {
       // lanes that share the channel chunk sc4 are N4 apart: fold them, then one atomic per channel per tile
       // (the launcher guarantees rows_per_image % 32 == 0, so a 32-row tile never straddles two images)
 #pragma unroll
@@ -185,6 +231,35 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
         for (int e = 0; e < 4; ++e) atomicAdd(dst + e, dsum[e]);
       }
     }
+  };
+  // The first tile is peeled: at the loop header the queue of outstanding memory operations then looks the same on
+  // entry and on the back edge (prefetch loads, residual loads, stores -- in that order), and the wait for the
+  // prefetched tile can leave the younger residual loads and stores in flight.
+  // (the loop must be reachable ONLY through the peeled iteration: any other path into its header carries the
+  // prologue's queue state and forces the conservative wait again)
+  if constexpr (D2) {
+    if (tile < ntiles) {
+      body(tile, A, g2);
+      tile += g1;
+      if (tile < ntiles) {
+        body(tile, Bq, g2);
+        tile += g1;
+        while (tile < ntiles) {
+          body(tile, A, g2);
+          tile += g1;
+          if (tile >= ntiles) break;
+          body(tile, Bq, g2);
+          tile += g1;
+        }
+      }
+    }
+  } else if constexpr (FAST) {
+    if (tile < ntiles) {
+      body(tile, A, g1);
+      for (tile += g1; tile < ntiles; tile += g1) body(tile, A, g1);
+    }
+  } else {
+    for (; tile < ntiles; tile += g1) body(tile, A, g1);
   }
 }
 
@@ -196,8 +271,15 @@ static void run_gemm_rows(const float* X, const float* W, const float* bias, con
   static const int rows_cap = [] { const char* e = getenv("MVAE_ROWS_GRID"); return e ? atoi(e) : 0; }();
   const int cap = rows_cap > 0 ? rows_cap : 2 * big_grid_cus();   // 2 resident workgroups per CU (register-limited)
   int grid = (int)(ntiles < cap ? ntiles : cap);
-  hipLaunchKernelGGL((k_gemm_rows<K, N, WT>), dim3(grid), dim3(256), 0, s, X, W, bias, residual, Y, M, rows_per_image,
-                     pre, act, dot_src, dot_out);
+  if (M % 128 == 0 && !dot_src && !residual)
+    hipLaunchKernelGGL((k_gemm_rows<K, N, WT, true, true>), dim3(grid), dim3(256), 0, s, X, W, bias, residual, Y, M,
+                       rows_per_image, pre, act, dot_src, dot_out);
+  else if (M % 128 == 0 && !dot_src)
+    hipLaunchKernelGGL((k_gemm_rows<K, N, WT, true, false>), dim3(grid), dim3(256), 0, s, X, W, bias, residual, Y, M,
+                       rows_per_image, pre, act, dot_src, dot_out);
+  else
+    hipLaunchKernelGGL((k_gemm_rows<K, N, WT, false, false>), dim3(grid), dim3(256), 0, s, X, W, bias, residual, Y, M,
+                       rows_per_image, pre, act, dot_src, dot_out);
 }
 
 // returns false when the shape is not covered (caller falls back to the generic kernel)
