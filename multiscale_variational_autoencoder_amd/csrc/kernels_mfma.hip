@@ -137,6 +137,18 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
     load_tile(tile, A);
     if constexpr (D2) load_tile(tile + g1 < ntiles ? tile + g1 : tile, Bq);
   }
+  // FAST with a residual: the residual of tile t+1 is fetched at the END of tile t's epilogue, into the registers tile t
+  // has just finished with -- a whole tile ahead of its use at no register cost (fetched at the start of its own tile
+  // it had one MFMA phase, less than the loaded HBM latency, to arrive).
+  f32x4 resq[ST];
+  auto load_res = [&](int64_t tile) {
+    const int64_t row0 = tile * 128 + wave * 32;
+#pragma unroll
+    for (int j = 0; j < ST; ++j) resq[j] = RS4[(row0 + j * RPS + sr) * N4 + sc4];
+  };
+  if constexpr (FAST && !D2) {
+    if (tile < ntiles) load_res(tile);
+  }
   // S holds this tile (fetched two iterations ago in FAST mode); it is refilled for tile + ahead once it is in LDS
   auto body = [&](int64_t tile, Stage& S, int64_t ahead) {    // everything below is wave-private: no block barrier
     const int64_t row0 = tile * 128 + wave * 32;
@@ -154,10 +166,6 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
     if constexpr (FAST) {
       // prefetch under the MFMAs; past the last tile the current one is fetched again (never used)
       load_tile(tile + ahead < ntiles ? tile + ahead : tile, S);
-      if constexpr (!D2) {
-#pragma unroll
-        for (int j = 0; j < ST; ++j) res[j] = RS4[(row0 + j * RPS + sr) * N4 + sc4];
-      }
     } else {
       if (tile + ahead < ntiles) load_tile(tile + ahead, S);
       if (residual) {
@@ -208,7 +216,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_apply_m(v[e], act);
       }
-      if constexpr (!D2) {
+      if constexpr (FAST && !D2) {
+        if (residual) v = v + resq[j];
+      } else if constexpr (!FAST) {
         if (residual) v = v + res[j];
       }
       if constexpr (FAST) {
@@ -218,6 +228,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
         if (dot_src) dsum += v * D4[row * N4 + sc4];
       }
     }
+    if constexpr (FAST && !D2) load_res(tile + ahead < ntiles ? tile + ahead : tile);
     if (!FAST && dot_src) {
       // lanes that share the channel chunk sc4 are N4 apart: fold them, then one atomic per channel per tile
       // (the launcher guarantees rows_per_image % 32 == 0, so a 32-row tile never straddles two images)
@@ -879,13 +890,20 @@ bool launch_conv_taps_mfma(bool transposed, const float* in, const float* w, con
 // GEMM fragments and the channel-on-lane wgrad reads alike.  Y leaves straight from the accumulator layout
 // (each store instruction = two full 128-byte row segments), residual and dot source are read in the same layout.
 // =================================================================================================
-template <int C>
+// MODE 0: general (run-time flags, ragged M).  MODE 1 / 2 are the two ways the MobileNetV3 backward calls it, for
+// M % TR == 0, as straight-line tile loops (see k_gemm_rows FAST: counted waits, first tile peeled):
+//   MODE 1 = conv2 pair: gate + dot, no residual;   MODE 2 = conv0 pair: residual, no gate, no dot.
+// In MODE 2 the next tile's residual is requested after this tile's outputs are formed but BEFORE they are stored:
+// vmcnt is one in-order queue, so a wait for any load issued behind the stores also waits for the stores' acknowledgement
+// (several us under load) -- every load a later wait needs is therefore issued ahead of the tile's stores.
+template <int C, int MODE>
 __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ X, const float* __restrict__ W,
                                                       const float* __restrict__ aux, const float* __restrict__ gate,
                                                       const float* __restrict__ residual, float* __restrict__ Y,
                                                       float* __restrict__ dW, float* __restrict__ db,
                                                       float* __restrict__ dot_out, int64_t M, int64_t rows_per_image,
                                                       int nslots, int64_t slot_stride) {
+  constexpr bool FAST = MODE != 0;
   constexpr int KH = C / 2, NT = C / 32, C4 = C / 4, MASK = C4 - 1;
   constexpr int WN = NT, WR = 4 / WN, TR = 32 * WR;        // block tile = TR rows
   constexpr int LD = TR * C4 / 256;                        // float4 per thread per tensor (= 4)
@@ -894,6 +912,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = wave % WN, rw = wave / WN, n0 = nw * 32;
   const int i = lane & 31, h = lane >> 5;
+  const bool has_gate = MODE == 1 || (MODE == 0 && gate != nullptr);
+  const bool has_res = MODE == 2 || (MODE == 0 && residual != nullptr);
+  const bool has_dot = MODE == 1 || (MODE == 0 && dot_out != nullptr);
   float breg[KH];                                          // Wt[k = h*KH + t][n = n0 + i], resident in registers
 #pragma unroll
   for (int t = 0; t < KH; ++t) breg[t] = W[(int64_t)(n0 + i) * C + h * KH + t];
@@ -914,20 +935,56 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
   auto load_tile = [&](int64_t tile) {                     // a tile is one contiguous run of TR*C floats
     const f32x4* px = X4 + tile * (TR * C4) + threadIdx.x;
     const f32x4* pa = A4 + tile * (TR * C4) + threadIdx.x;
-    const int64_t left = M - tile * TR;
-    const int lim = left < TR ? (int)left : TR;            // valid rows in this tile
+    if constexpr (FAST) {
 #pragma unroll
-    for (int j = 0; j < LD; ++j) {
-      const bool ok = (j * 256 + (int)threadIdx.x) / C4 < lim;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      stx[j] = ok ? px[j * 256] : z;
-      sta[j] = ok ? pa[j * 256] : z;
+      for (int j = 0; j < LD; ++j) { stx[j] = px[j * 256]; sta[j] = pa[j * 256]; }
+    } else {
+      const int64_t left = M - tile * TR;
+      const int lim = left < TR ? (int)left : TR;          // valid rows in this tile
+#pragma unroll
+      for (int j = 0; j < LD; ++j) {
+        const bool ok = (j * 256 + (int)threadIdx.x) / C4 < lim;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        stx[j] = ok ? px[j * 256] : z;
+        sta[j] = ok ? pa[j * 256] : z;
+      }
+    }
+  };
+  // residual in the accumulator layout, one tile ahead (into the registers the previous tile has finished with)
+  float res[16];
+  auto load_res = [&](int64_t tile) {
+    const int64_t row0 = tile * TR + rw * 32;
+    const float* pr = residual + (row0 + 4 * h) * C + n0 + i;
+    if constexpr (FAST) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) res[r] = pr[((r & 3) + 8 * (r >> 2)) * C];
+    } else {
+      const int64_t left = M - row0 - 4 * h;
+      const int lim = left < 32 ? (int)left : 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) res[r] = pr[((r & 3) + 8 * (r >> 2)) < lim ? ((r & 3) + 8 * (r >> 2)) * C : 0];
     }
   };
   int64_t tile = blockIdx.x;
-  if (tile < ntiles) load_tile(tile);
-  for (; tile < ntiles; tile += gridDim.x) {
+  if (tile < ntiles) {
+    load_tile(tile);
+    if constexpr (MODE == 2) load_res(tile);
+    else if constexpr (MODE == 0) { if (residual) load_res(tile); }
+  }
+  auto body = [&](int64_t tile) {
     const int64_t row0 = tile * TR + rw * 32;              // this wave's 32 rows
+    const int64_t next = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
+    // squeeze-excite gate: lane half h reads fragment rows 16h .. 16h+15 of the wave's 32 -- one image per half when
+    // rows_per_image % 16 == 0.  Requested first thing: the loads then sit AHEAD of the next tile's prefetch in the
+    // in-order vmcnt queue, and the wait before the weight-gradient MFMAs leaves that prefetch in flight.
+    const int64_t rowh = FAST ? row0 + 16 * h : (row0 + 16 * h < M ? row0 + 16 * h : row0);
+    float gl[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      if constexpr (MODE == 1) gl[kt] = gate[(rowh / rows_per_image) * C + kt * 32 + i];
+      else if constexpr (MODE == 2) gl[kt] = 1.0f;
+      else gl[kt] = (gate && row0 < M) ? gate[(rowh / rows_per_image) * C + kt * 32 + i] : 1.0f;
+    }
     __syncthreads();                                       // previous tile fully consumed by all waves
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
@@ -937,18 +994,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
       reinterpret_cast<f32x4*>(sA)[SWZ4(r, c4)] = sta[j];
     }
     __syncthreads();
-    if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);          // prefetch under the MFMAs
-    // the residual is fetched in the accumulator layout BEFORE both MFMA phases: its HBM latency (2-3 us under load)
-    // is longer than one phase
+    if constexpr (FAST) load_tile(next);                   // prefetch under the MFMAs (past the end: refetch, unused)
+    else if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
     const int64_t left = M - row0 - 4 * h;
-    const int lim = left < 32 ? (int)left : 32;            // row (r&3)+8(r>>2) of this lane half is valid below lim
+    const int lim = FAST ? 32 : (left < 32 ? (int)left : 32);   // row (r&3)+8(r>>2) of this lane half is valid below lim
     const int64_t ebase = (row0 + 4 * h) * C + n0 + i;
-    float res[16];
-    if (residual) {
-      const float* pr = residual + ebase;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) res[r] = pr[((r & 3) + 8 * (r >> 2)) < lim ? ((r & 3) + 8 * (r >> 2)) * C : 0];
-    }
     // ---- Y tile = X . Wt   (32 rows x 32 columns per wave)
     f32x16 acc;
 #pragma unroll
@@ -965,12 +1015,6 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[q * 4 + e], acc, 0, 0, 0);
     }
     // ---- dW[:, n0..n0+31] += (aux * gate)^T X over the wave's 32 rows (lane half h: rows 16h .. 16h+15)
-    // lane half h reads fragment rows 16h .. 16h+15 of the wave's 32: one image per half when rows_per_image % 16 == 0
-    const int64_t rowh = row0 + 16 * h < M ? row0 + 16 * h : row0;
-    float gl[NT];
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-      gl[kt] = (gate && row0 < M) ? gate[(rowh / rows_per_image) * C + kt * 32 + i] : 1.0f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       float av[8][NT], bv[8];
@@ -991,24 +1035,38 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
       }
     }
     // ---- epilogue straight from the accumulator layout
+    if (has_res) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += res[r];
+    }
+    if constexpr (MODE == 2) load_res(next);               // ahead of the stores (see the header comment)
     float dsum[2] = {0.f, 0.f};                            // accumulator rows < 16 / >= 16: one image each
     float* py = Y + ebase;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rc = (r & 3) + 8 * (r >> 2);
-      float v = acc[r];
-      if (residual) v += res[r];
-      if (rc < lim) {
-        py[rc * C] = v;
-        if (dot_out) dsum[r >> 3] += v * sA[SWZ1(rw * 32 + rc + 4 * h, n0 + i)];
+      if (FAST || rc < lim) {
+        py[rc * C] = acc[r];
+        if (has_dot) dsum[r >> 3] += acc[r] * sA[SWZ1(rw * 32 + rc + 4 * h, n0 + i)];
       }
     }
-    if (dot_out) {
+    if (has_dot) {
       dsum[0] += __shfl_xor(dsum[0], 32, 64);
       dsum[1] += __shfl_xor(dsum[1], 32, 64);
-      if (h == 0 && row0 < M) atomicAdd(dot_out + (row0 / rows_per_image) * C + n0 + i, dsum[0]);
-      if (h == 1 && row0 + 16 < M) atomicAdd(dot_out + ((row0 + 16) / rows_per_image) * C + n0 + i, dsum[1]);
+      if (h == 0 && (FAST || row0 < M)) atomicAdd(dot_out + (row0 / rows_per_image) * C + n0 + i, dsum[0]);
+      if (h == 1 && (FAST || row0 + 16 < M)) atomicAdd(dot_out + ((row0 + 16) / rows_per_image) * C + n0 + i, dsum[1]);
     }
+    if constexpr (MODE == 0) {
+      if (residual && tile + gridDim.x < ntiles) load_res(tile + gridDim.x);
+    }
+  };
+  if constexpr (FAST) {                                    // the loop is reachable only through the peeled first tile
+    if (tile < ntiles) {
+      body(tile);
+      for (tile += gridDim.x; tile < ntiles; tile += gridDim.x) body(tile);
+    }
+  } else {
+    for (; tile < ntiles; tile += gridDim.x) body(tile);
   }
   // ---- reduce the row groups' dW slabs through LDS, then one coalesced float-atomic set per block
   float* red = sX;                                         // C*C floats <= TR*C
@@ -1048,8 +1106,14 @@ static void run_gemm_dual(const float* X, const float* W, const float* aux, cons
   int64_t ntiles = (M + TR - 1) / TR;
   const int cap = 2 * big_grid_cus();                      // 2 resident blocks per CU
   int grid = (int)(ntiles < cap ? ntiles : cap);
-  hipLaunchKernelGGL((k_gemm_dual<C>), dim3(grid), dim3(256), 0, s, X, W, aux, gate, residual, Y, sl.at(dW), sl.at(db),
-                     dot_out, M, rpi, sl.count(), sl.stride);
+#define MVAE_DUAL(MODE)                                                                                              \
+  hipLaunchKernelGGL((k_gemm_dual<C, MODE>), dim3(grid), dim3(256), 0, s, X, W, aux, gate, residual, Y, sl.at(dW),   \
+                     sl.at(db), dot_out, M, rpi, sl.count(), sl.stride)
+  const bool full = M % TR == 0;
+  if (full && gate && dot_out && !residual) MVAE_DUAL(1);
+  else if (full && residual && !gate && !dot_out) MVAE_DUAL(2);
+  else MVAE_DUAL(0);
+#undef MVAE_DUAL
 }
 
 // conv (1x1, C -> C) backward pair in one pass; false = shape not covered

@@ -36,9 +36,7 @@ struct ProfScope {
     ProfRec r;
     if (p.by_size) {
       char buf[96];
-      int lg = 0;
-      while ((1ll << lg) < (long long)bytes) ++lg;
-      snprintf(buf, sizeof(buf), "%s#%dB/q%d", tag, lg, p.cur_scale);
+      snprintf(buf, sizeof(buf), "%s#%.0fMB/q%d", tag, bytes / 1e6, p.cur_scale);
       r.tag = p.tag_id(buf);
     } else {
       r.tag = p.tag_id(tag);
