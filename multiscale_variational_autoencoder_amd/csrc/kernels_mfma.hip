@@ -207,28 +207,42 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
       for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + nt * 32 + i] = acc[nt][r];
     WAVE_LDS_SYNC();
     f32x4 dsum = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FAST) {
+      // all outputs are formed first; the next tile's residual is then requested BEFORE the stores (vmcnt is one
+      // in-order queue: a wait for a load issued behind the stores would also wait for their acknowledgement)
+      f32x4 vout[ST];
 #pragma unroll
-    for (int j = 0; j < ST; ++j) {
-      const int r = j * RPS + sr;
-      int64_t row = row0 + r;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&sT[r * TS + sc4 * 4]) + bias4;
-      if (act != ACT_NONE) {
+      for (int j = 0; j < ST; ++j) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&sT[(j * RPS + sr) * TS + sc4 * 4]) + bias4;
+        if (act != ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply_m(v[e], act);
+          for (int e = 0; e < 4; ++e) v[e] = act_apply_m(v[e], act);
+        }
+        if constexpr (!D2) {
+          if (residual) v = v + resq[j];
+        }
+        vout[j] = v;
       }
-      if constexpr (FAST && !D2) {
-        if (residual) v = v + resq[j];
-      } else if constexpr (!FAST) {
+      if constexpr (!D2) load_res(tile + ahead < ntiles ? tile + ahead : tile);
+#pragma unroll
+      for (int j = 0; j < ST; ++j) Y4[(row0 + j * RPS + sr) * N4 + sc4] = vout[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < ST; ++j) {
+        const int r = j * RPS + sr;
+        int64_t row = row0 + r;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&sT[r * TS + sc4 * 4]) + bias4;
+        if (act != ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_apply_m(v[e], act);
+        }
         if (residual) v = v + res[j];
-      }
-      if constexpr (FAST) {
-        Y4[row * N4 + sc4] = v;
-      } else if (row < M) {
-        Y4[row * N4 + sc4] = v;
-        if (dot_src) dsum += v * D4[row * N4 + sc4];
+        if (row < M) {
+          Y4[row * N4 + sc4] = v;
+          if (dot_src) dsum += v * D4[row * N4 + sc4];
+        }
       }
     }
-    if constexpr (FAST && !D2) load_res(tile + ahead < ntiles ? tile + ahead : tile);
     if (!FAST && dot_src) {
       // lanes that share the channel chunk sc4 are N4 apart: fold them, then one atomic per channel per tile
       // (the launcher guarantees rows_per_image % 32 == 0, so a 32-row tile never straddles two images)
