@@ -846,16 +846,23 @@ __global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in,
     __builtin_amdgcn_sched_barrier(0);
     if (more) store_w((it + 1) & 1);
   }
+  // epilogue: the bias comes from an UNCONDITIONAL load and the 16 row offsets are read from LDS up front.  With the
+  // bias load inside `if (bias)`, every exec-masked store block below carried its own s_waitcnt vmcnt(0) -- i.e. each of
+  // the 32 stores of a wave waited for the previous store's acknowledgement.
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias ? bias : W)[nt * 32 + i];
   __syncthreads();     // sOff visible (also when ntaps == 0)
+  int64_t offs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) offs[r] = sOff[wave][(r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = nt * 32 + i;
-    const float bv = bias ? bias[n] : 0.f;
+    const float b = bias ? bv[nt] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int64_t off = sOff[wave][(r & 3) + 8 * (r >> 2) + 4 * h];
-      if (off >= 0) out[off + n] = acc[nt][r] + bv;
-    }
+    for (int r = 0; r < 16; ++r)
+      if (offs[r] >= 0) out[offs[r] + n] = acc[nt][r] + b;
   }
 }
 
