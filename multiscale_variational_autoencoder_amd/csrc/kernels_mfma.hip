@@ -952,8 +952,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
     for (int r = 0; r < 16; ++r) accw[kt][r] = 0.f;
   float bsum = 0.f;
 
-  f32x4 stx[LD], sta[LD];
-  auto load_tile = [&](int64_t tile) {                     // a tile is one contiguous run of TR*C floats
+  // MODE 1 (no residual registers) at C = 32 runs TWO tiles of prefetch ahead, buffers S0 / S1 alternating (the conv2
+  // pair has only its two input streams in flight; k_gemm_rows D2, same finding)
+  constexpr bool D2 = MODE == 1 && C <= 32;                // at C = 64 the second buffer does not fit (61 spills)
+  struct Stage { f32x4 x[LD], a[LD]; };
+  Stage S0, S1;
+  auto load_tile = [&](int64_t tile, Stage& S) {           // a tile is one contiguous run of TR*C floats
+    f32x4 (&stx)[LD] = S.x;
+    f32x4 (&sta)[LD] = S.a;
     const f32x4* px = X4 + tile * (TR * C4) + threadIdx.x;
     const f32x4* pa = A4 + tile * (TR * C4) + threadIdx.x;
     if constexpr (FAST) {
@@ -987,14 +993,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
     }
   };
   int64_t tile = blockIdx.x;
+  const int64_t g1 = gridDim.x, ahead = D2 ? 2 * g1 : g1;
   if (tile < ntiles) {
-    load_tile(tile);
+    load_tile(tile, S0);
+    if constexpr (D2) load_tile(tile + g1 < ntiles ? tile + g1 : tile, S1);
     if constexpr (MODE == 2) load_res(tile);
     else if constexpr (MODE == 0) { if (residual) load_res(tile); }
   }
-  auto body = [&](int64_t tile) {
+  auto body = [&](int64_t tile, Stage& S) {
     const int64_t row0 = tile * TR + rw * 32;              // this wave's 32 rows
-    const int64_t next = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
+    const int64_t next = tile + ahead < ntiles ? tile + ahead : tile;
     // squeeze-excite gate: lane half h reads fragment rows 16h .. 16h+15 of the wave's 32 -- one image per half when
     // rows_per_image % 16 == 0.  Requested first thing: the loads then sit AHEAD of the next tile's prefetch in the
     // in-order vmcnt queue, and the wait before the weight-gradient MFMAs leaves that prefetch in flight.
@@ -1011,12 +1019,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
     for (int j = 0; j < LD; ++j) {
       const int idx = j * 256 + threadIdx.x;
       const int r = idx / C4, c4 = idx % C4;
-      reinterpret_cast<f32x4*>(sX)[SWZ4(r, c4)] = stx[j];
-      reinterpret_cast<f32x4*>(sA)[SWZ4(r, c4)] = sta[j];
+      reinterpret_cast<f32x4*>(sX)[SWZ4(r, c4)] = S.x[j];
+      reinterpret_cast<f32x4*>(sA)[SWZ4(r, c4)] = S.a[j];
     }
     __syncthreads();
-    if constexpr (FAST) load_tile(next);                   // prefetch under the MFMAs (past the end: refetch, unused)
-    else if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    if constexpr (FAST) load_tile(next, S);                // prefetch under the MFMAs (past the end: refetch, unused)
+    else if (tile + g1 < ntiles) load_tile(tile + g1, S);
     const int64_t left = M - row0 - 4 * h;
     const int lim = FAST ? 32 : (left < 32 ? (int)left : 32);   // row (r&3)+8(r>>2) of this lane half is valid below lim
     const int64_t ebase = (row0 + 4 * h) * C + n0 + i;
@@ -1024,31 +1032,35 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    {
-      f32x4 afr[KH / 4];
+    constexpr int QH = KH / 8 > 0 ? KH / 8 : 1, NB = (KH / 4) / QH;      // fragments in two batches: half the registers
 #pragma unroll
-      for (int q = 0; q < KH / 4; ++q)
-        afr[q] = reinterpret_cast<const f32x4*>(sX)[SWZ4(rw * 32 + i, h * (C4 / 2) + q)];
+    for (int bq = 0; bq < NB; ++bq) {
+      f32x4 afr[QH];
+#pragma unroll
+      for (int q = 0; q < QH; ++q)
+        afr[q] = reinterpret_cast<const f32x4*>(sX)[SWZ4(rw * 32 + i, h * (C4 / 2) + bq * QH + q)];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < KH / 4; ++q)
+      for (int q = 0; q < QH; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[q * 4 + e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[(bq * QH + q) * 4 + e], acc, 0, 0, 0);
     }
     // ---- dW[:, n0..n0+31] += (aux * gate)^T X over the wave's 32 rows (lane half h: rows 16h .. 16h+15)
+    constexpr int TB = D2 ? 4 : 8;                          // row pairs per operand batch (D2 is short of registers)
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float av[8][NT], bv[8];
+    for (int part = 0; part < 16 / TB; ++part) {
+      float av[TB][NT], bv[TB];
 #pragma unroll
-      for (int tt = 0; tt < 8; ++tt) {
-        const int r = rw * 32 + h * 16 + half * 8 + tt;
+      for (int tt = 0; tt < TB; ++tt) {
+        const int r = rw * 32 + h * 16 + part * TB + tt;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) av[tt][kt] = sA[SWZ1(r, kt * 32 + i)] * gl[kt];
         bv[tt] = sX[SWZ1(r, n0 + i)];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int tt = 0; tt < 8; ++tt) {
+      for (int tt = 0; tt < TB; ++tt) {
         bsum += bv[tt];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
@@ -1078,16 +1090,32 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
       if (h == 1 && (FAST || row0 + 16 < M)) atomicAdd(dot_out + ((row0 + 16) / rows_per_image) * C + n0 + i, dsum[1]);
     }
     if constexpr (MODE == 0) {
-      if (residual && tile + gridDim.x < ntiles) load_res(tile + gridDim.x);
+      if (residual && tile + g1 < ntiles) load_res(tile + g1);
     }
   };
-  if constexpr (FAST) {                                    // the loop is reachable only through the peeled first tile
+  if constexpr (D2) {                                      // loops reachable only through the peeled first tile(s)
     if (tile < ntiles) {
-      body(tile);
-      for (tile += gridDim.x; tile < ntiles; tile += gridDim.x) body(tile);
+      body(tile, S0);
+      tile += g1;
+      if (tile < ntiles) {
+        body(tile, S1);
+        tile += g1;
+        while (tile < ntiles) {
+          body(tile, S0);
+          tile += g1;
+          if (tile >= ntiles) break;
+          body(tile, S1);
+          tile += g1;
+        }
+      }
+    }
+  } else if constexpr (FAST) {
+    if (tile < ntiles) {
+      body(tile, S0);
+      for (tile += g1; tile < ntiles; tile += g1) body(tile, S0);
     }
   } else {
-    for (; tile < ntiles; tile += gridDim.x) body(tile);
+    for (; tile < ntiles; tile += g1) body(tile, S0);
   }
   // ---- reduce the row groups' dW slabs through LDS, then one coalesced float-atomic set per block
   float* red = sX;                                         // C*C floats <= TR*C
