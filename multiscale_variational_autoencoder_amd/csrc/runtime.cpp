@@ -508,7 +508,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   float* bufB = acquire(h, sc, s);
   bool dual2;
   {
-    ProfScope ps(c == 64 ? "k_gemm_dual<64>" : "k_gemm_dual<32>", 12.0 * B * HW * c, 4.0 * B * HW * c * c, s);
+    ProfScope ps(c == 64 ? "k_gemm_dual<64, 1>" : "k_gemm_dual<32, 1>", 12.0 * B * HW * c, 4.0 * B * HW * c * c, s);   // rocprof kernel names
     // dt2 = dout . W2^T ; dW2 += (t1*g)^T dout ; db2 ; dg = sum_hw dt2 * t1     -- one pass over (dout, t1)
     dual2 = launch_gemm_dual_mfma(dout, P + m.w2, m.t1, m.g, nullptr, bufB, G + m.w2, G + m.b2, dg, (int64_t)B * HW, HW,
                                   c, h->gslots, s);
@@ -553,7 +553,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   }
   bool dual0;
   {
-    ProfScope ps(c == 64 ? "k_gemm_dual<64>" : "k_gemm_dual<32>", 16.0 * B * HW * c, 4.0 * B * HW * c * c, s);
+    ProfScope ps(c == 64 ? "k_gemm_dual<64, 2>" : "k_gemm_dual<32, 2>", 16.0 * B * HW * c, 4.0 * B * HW * c * c, s);
     // da = dt0pre . W0^T + dout ; dW0 += a^T dt0pre ; db0     -- one pass over (dt0pre, a, dout)
     dual0 = launch_gemm_dual_mfma(bufC, P + m.w0, x, nullptr, dout, bufB, G + m.w0, G + m.b0, nullptr, (int64_t)B * HW, HW,
                                   c, h->gslots, s);
