@@ -143,6 +143,18 @@ def main():
         dt = float(t.item())
     m = eng.metrics()
     finite = bool(np.isfinite(m["r_exp"]) and np.isfinite(m["vae_kl_loss"]))
+    # "also report forward+backward+ELBO without the optimiser" (secondary number, single GPU only)
+    fb_ms = None
+    if world == 1:
+        nfb = max(min(args.steps, 10), 1)
+        for i in range(2):
+            eng.forward(x, True, seed=5000 + i, outputs=()); eng.backward(rf, kf)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(nfb):
+            eng.forward(x, True, seed=6000 + i, outputs=()); eng.backward(rf, kf)
+        torch.cuda.synchronize()
+        fb_ms = 1e3 * (time.perf_counter() - t1) / nfb
 
     # ---- per-kernel durations, live, with HIP events on the launch stream (instrumented extra steps)
     roofline, kernels = None, None
@@ -194,6 +206,8 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "collective": "1 RCCL all-reduce of %d floats per step" % eng.R if world > 1 else "none"},
         "finite": finite,
+        "fwd_bwd_only": None if fb_ms is None else {"ms_per_step": fb_ms, "images_per_sec": B / (fb_ms * 1e-3)},
+        "elbo_metrics": {k: float(v) for k, v in m.items()},
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "hbm_frac": step_bytes / (dt / args.steps) / HBM_PEAK,
                           "fp32_flop_frac": 3 * w["F"] * B / (dt / args.steps) / FP32_PEAK},
         "roofline": roofline,
