@@ -104,10 +104,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    # rehearsal of the N > 1 path on a one-GPU box (MVAE_BENCH_REHEARSE=gloo): every rank uses cuda:0 and the
+    # all-reduce goes through gloo -- exercises rank handling, the all-reduce of the reduce arena and the JSON line,
+    # not RCCL performance.  The driver's real runs use backend "nccl" (= RCCL), one rank per GPU.
+    rehearse = os.environ.get("MVAE_BENCH_REHEARSE", "")
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group(rehearse, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from multiscale_variational_autoencoder_amd.engine import Engine
     from multiscale_variational_autoencoder_amd.initializers import init_params
