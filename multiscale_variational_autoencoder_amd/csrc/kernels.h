@@ -154,12 +154,14 @@ void launch_loss_bwd(const float* y, const float* recon, const float* merged, co
 void launch_metrics(const float* losses, int ncol, int B, float* metrics, hipStream_t s);
 
 // ---- optimiser (multiscale_vae.py:497-499) ----
-struct ChunkDesc { int64_t offset; int32_t len; int32_t tensor; int32_t reg; int32_t pad; };
+// first / count: the contiguous run of chunks that make up this chunk's tensor (for the deterministic norm)
+struct ChunkDesc { int64_t offset; int32_t len; int32_t tensor; int32_t reg; int32_t pad; int32_t first; int32_t count; };
 // zero / fold the gradient-slot copies of the listed (single-chunk) tensors
 void launch_slot_zero(const ChunkDesc* chunks, int nchunks, float* slots, int64_t stride, int n, hipStream_t s);
 void launch_slot_sum(const ChunkDesc* chunks, int nchunks, float* g, const float* slots, int64_t stride, int n,
                      hipStream_t s);
-// g = g*grad_scale + reg'(w) ; norms[tensor] += sum g^2
+// g = g*grad_scale + reg'(w) ; norms[chunk] = sum over the chunk of g^2 (plain store: the per-tensor norm is then summed
+// in a fixed order by the apply pass, so every data-parallel replica computes bit-identical clip factors)
 void launch_opt_prepare(const float* w, float* g, const ChunkDesc* chunks, int nchunks, float* norms,
                         float grad_scale, hipStream_t s);
 // clip per tensor ; a += g^2 ; w -= lr * g / (sqrt(a) + 1e-7)

@@ -1115,7 +1115,7 @@ __global__ void __launch_bounds__(256) k_opt_prepare(const float* __restrict__ w
     acc += gv * gv;
   }
   float t = block_sum(acc, sh);
-  if (threadIdx.x == 0) atomicAdd(&norms[cd.tensor], t);
+  if (threadIdx.x == 0) norms[blockIdx.x] = t;        // per-chunk partial, summed in order by k_opt_apply
 }
 void launch_opt_prepare(const float* w, float* g, const ChunkDesc* chunks, int nchunks, float* norms,
                         float grad_scale, hipStream_t s) {
@@ -1128,7 +1128,11 @@ __global__ void __launch_bounds__(256) k_opt_apply(float* __restrict__ w, const 
   ChunkDesc cd = chunks[blockIdx.x];
   float f = 1.0f;
   if (clip_norm > 0.f) {
-    float nrm = sqrtf(norms[cd.tensor]);
+    // ||g||^2 of the whole tensor: its chunks' partial sums in a FIXED order (no float atomics: the clip factor, and with
+    // it the parameter update, is bit-identical on every replica of a data-parallel run)
+    float sq = 0.f;
+    for (int j = 0; j < cd.count; ++j) sq += norms[cd.first + j];
+    const float nrm = sqrtf(sq);
     f = clip_norm / fmaxf(nrm, clip_norm);       // tf.clip_by_norm
   }
   for (int i = threadIdx.x; i < cd.len; i += blockDim.x) {

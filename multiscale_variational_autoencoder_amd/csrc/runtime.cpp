@@ -344,11 +344,14 @@ int build_plan(mvae_handle* h) {
   // optimiser tables
   for (size_t t = 0; t < h->params.size(); ++t) {
     const ParamInfo& p = h->params[t];
+    const int32_t first = (int32_t)h->chunks.size();
+    const int32_t count = (int32_t)((p.elems + kChunk - 1) / kChunk);
     for (int64_t o = 0; o < p.elems; o += kChunk) {
       ChunkDesc cd;
       cd.offset = p.offset + o;
       cd.len = (int32_t)((p.elems - o) < kChunk ? (p.elems - o) : kChunk);
       cd.tensor = (int32_t)t; cd.reg = p.reg; cd.pad = 0;
+      cd.first = first; cd.count = count;
       h->chunks.push_back(cd);
     }
   }
@@ -364,7 +367,7 @@ int build_plan(mvae_handle* h) {
   h->off_chunks = b.ws_alloc((int64_t)(h->chunks.size() * sizeof(ChunkDesc) + 3) / 4);
   h->off_slot_chunks = b.ws_alloc((int64_t)(h->slot_chunks.size() * sizeof(ChunkDesc) + 3) / 4);
   h->off_sdescs = b.ws_alloc((int64_t)(h->sdescs.size() * sizeof(StateDesc) + 3) / 4);
-  h->off_norms = b.ws_alloc((int64_t)h->params.size());
+  h->off_norms = b.ws_alloc((int64_t)h->chunks.size());          // one partial ||g||^2 per chunk
   h->off_seed = b.ws_alloc(kAlign);
   h->off_slots = b.ws_alloc((int64_t)kGradSlots * h->P);
   h->ws_floats = b.wcur;
@@ -1112,7 +1115,6 @@ int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_sca
   hipStream_t s0 = static_cast<hipStream_t>(stream);
   const int Bt = h->last_train_B;
   auto body = [=](hipStream_t s) {
-    launch_zero(h->d_norms, (int64_t)(h->params.size()), s);
     launch_opt_prepare(h->dp, h->dr, h->d_chunks, (int)h->chunks.size(), h->d_norms, grad_scale, s);
     launch_opt_apply(h->dp, h->dr, h->da, h->d_chunks, (int)h->chunks.size(), h->d_norms, lr, clip_norm, s);
     // BN moving statistics from the (all-reduced, hence grad_scale) batch statistics
