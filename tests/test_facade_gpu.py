@@ -76,9 +76,21 @@ def test_checkpoint_resume_reproduces_the_run(tmp_path):
             assert np.array_equal(b.get_weights()[k[2:]], v)
     b.train(x, batch_size=16, epochs=2, run_folder=None, initial_epoch=1)
     wb = b.get_weights()
-    # same shuffles, same device RNG stream, same optimiser state: equal up to float-atomic summation order
-    worst = max(rel_err(wb[k], wa[k]) for k in wa if wa[k].size > 64)
-    assert worst < 2e-2, worst
+    # same shuffles, same device RNG stream, same optimiser state: the resumed epoch retraces the original one up to
+    # float-atomic summation order.  Measured against the distance the parameters travel in that epoch (tensors whose
+    # true gradient is identically zero -- biases feeding BatchNorm -- random-walk on rounding noise, so a per-tensor
+    # relative error is meaningless for them; an optimiser state that was NOT restored moves the result by O(1) here).
+    w0 = {k[2:]: v for k, v in np.load(ck).items() if k.startswith("w/")}
+    flat = lambda d: np.concatenate([np.asarray(d[k], np.float64).ravel() for k in wa])
+    travelled = np.linalg.norm(flat(wa) - flat(w0))
+    dist = np.linalg.norm(flat(wb) - flat(wa))
+    assert travelled > 0 and dist <= 0.15 * travelled, (dist, travelled)
+    # a run resumed WITHOUT the Adagrad accumulators / RNG position does not retrace it
+    c = _vae()
+    c.compile(learning_rate=0.01, r_loss_factor=1000, kl_loss_factor=10)
+    c.set_weights(w0)
+    c.train(x, batch_size=16, epochs=2, run_folder=None, initial_epoch=1)
+    assert np.linalg.norm(flat(c.get_weights()) - flat(wa)) > 2.0 * dist
 
 
 def test_train_on_batch_matches_one_oracle_step():
