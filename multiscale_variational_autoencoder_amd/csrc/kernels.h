@@ -182,7 +182,7 @@ void launch_bn2d_mean(const float* sum, const float* mov_mean, float* mean, int6
 bool launch_convbase_fwd(const float* in, const float* W, const float* bias, float* out, int B, int H, int Wd, int CI,
                          int CO, hipStream_t s);
 bool launch_convbase_wgrad(const float* in, const float* dy, const float* y, float* dW, float* db, int B, int H, int Wd,
-                           int CI, int CO, hipStream_t s);
+                           int CI, int CO, GradSlots sl, hipStream_t s);
 bool launch_head_fwd(const float* x, const float* scale, const float* shift, const float* W, const float* bias,
                      float* y, int64_t M, int dc, int C, hipStream_t s);
 // squeeze-excite branch in two forward / two backward launches (kernels_se.hip); part: [se_max_blocks(B)][2][C] floats

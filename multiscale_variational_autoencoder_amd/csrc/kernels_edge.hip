@@ -111,6 +111,12 @@ __global__ void __launch_bounds__(256) k_convbase_wgrad(const float* __restrict_
 }
 
 typedef float f32x16e __attribute__((ext_vector_type(16)));
+// exp(v) - 1 for v <= 0 to ~1e-7 ABSOLUTE error (fp32 resolution of the O(1) activations it feeds): cubic near zero
+// (truncation < v^4/24 = 3.4e-8 at -0.03), hardware exp below.  libm's expm1f is ~40 instructions per element and made
+// this 3 -> 32 channel kernel VALU-bound (16 calls per lane per 32-pixel tile).
+__device__ __forceinline__ float elu_neg(float v) {
+  return v > -0.03f ? v * (1.0f + v * (0.5f + v * 0.16666667f)) : __expf(v) - 1.0f;
+}
 // MFMA form of the conv_base forward for 9*CI <= 32: out[32 pixels][32 co] = patch[32 pixels][9*CI] . W[9*CI][32],
 // two patch elements per v_mfma_f32_32x32x2_f32 (lane half h takes element 2s + h).  A wave owns 32 consecutive
 // pixels; W (one column per lane) stays in registers; the patch loads are raw + clamped, issued ahead of the MFMAs;
@@ -166,7 +172,7 @@ __global__ void __launch_bounds__(256) k_convbase_fwd_mfma(const float* __restri
     for (int r = 0; r < 16; ++r) {
       const int rc = (r & 3) + 8 * (r >> 2);
       float v = acc[r] + bz;
-      v = v > 0.f ? v : expm1f(v);
+      v = v > 0.f ? v : elu_neg(v);
       if (rc < lim) po[rc * 32] = v;
     }
   }
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(256) k_convbase_fwd_mfma(const float* __restri
 __global__ void __launch_bounds__(256) k_convbase_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ dy,
                                                              const float* __restrict__ y, float* __restrict__ dW,
                                                              float* __restrict__ db, int B, int H, int Wd, int CI,
-                                                             int rows_per_wave) {
+                                                             int rows_per_wave, int nslots, int64_t slot_stride) {
   __shared__ float red[4][16][64];
   __shared__ float redb[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -229,13 +235,14 @@ __global__ void __launch_bounds__(256) k_convbase_wgrad_mfma(const float* __rest
   bsum += __shfl_xor(bsum, 32, 64);
   if (h == 0) redb[wave][i] = bsum;
   __syncthreads();
+  const int64_t gslot = (int64_t)(blockIdx.x % nslots) * slot_stride;     // gradient slot (kernels.h: GradSlots)
   if (wave == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = (r & 3) + 8 * (r >> 2) + 4 * h;          // patch element (row of D), column = co = i
-      if (k < KP) atomicAdd(&dW[k * 32 + i], red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane]);
+      if (k < KP) atomicAdd(&dW[gslot + k * 32 + i], red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane]);
     }
-    if (h == 0) atomicAdd(&db[i], redb[0][i] + redb[1][i] + redb[2][i] + redb[3][i]);
+    if (h == 0) atomicAdd(&db[gslot + i], redb[0][i] + redb[1][i] + redb[2][i] + redb[3][i]);
   }
 }
 
@@ -439,15 +446,15 @@ bool launch_convbase_fwd(const float* in, const float* W, const float* bias, flo
   return true;
 }
 bool launch_convbase_wgrad(const float* in, const float* dy, const float* y, float* dW, float* db, int B, int H, int Wd,
-                           int CI, int CO, hipStream_t s) {
+                           int CI, int CO, GradSlots sl, hipStream_t s) {
   if (CO != 32 || CI > 4) return false;
   if (9 * CI <= 32) {
     const int64_t nrows = (int64_t)B * H;
     int rpw = 1;
     while (nrows / rpw > 4096) rpw *= 2;            // <= 4096 waves: bounds the float-atomic traffic
     const int64_t waves = (nrows + rpw - 1) / rpw;
-    hipLaunchKernelGGL(k_convbase_wgrad_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in, dy, y, dW, db, B,
-                       H, Wd, CI, rpw);
+    hipLaunchKernelGGL(k_convbase_wgrad_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in, dy, y, sl.at(dW),
+                       sl.at(db), B, H, Wd, CI, rpw, sl.count(), sl.stride);
     return true;
   }
   int64_t M = (int64_t)B * H * Wd;

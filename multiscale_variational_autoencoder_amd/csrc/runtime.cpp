@@ -1084,7 +1084,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     {
       ProfScope ps("convbase_wgrad", 4.0 * M * (2.0 * kConvBaseFilters + C), 2.0 * M * 9 * C * kConvBaseFilters, s);
       fused_base = launch_convbase_wgrad(sc.band, d, sc.e0, G + sc.cb_w, G + sc.cb_b, B, sc.H, sc.W, C,
-                                         kConvBaseFilters, s);
+                                         kConvBaseFilters, h->gslots, s);
     }
     wgrad_join(h, sc, s);                       // every side-stream weight gradient of this scale is done
     if (!fused_base) {
