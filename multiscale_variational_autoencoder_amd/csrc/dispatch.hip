@@ -48,7 +48,7 @@ bool launch_dw_bwd_data_opt(const float*, const float*, const float*, float*, in
 bool launch_dw_wgrad_opt(const float*, const float*, float*, float*, int, int, int, int, hipStream_t);
 bool launch_conv_taps_mfma(bool transposed, const float* in, const float* w, const float* bias, float* out,
                            const ConvGeom& g, hipStream_t s);
-bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, PreOp pre,
+bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, PreOp pre, GradSlots sl,
                             hipStream_t s);
 
 void launch_conv_f(const float* big, const float* w, const float* bias, const float* residual, float* small,
@@ -69,11 +69,11 @@ void launch_conv_t(const float* small, const float* w, const float* bias, const 
   if (g.KH * g.KW > 1 && !residual && launch_conv_taps_mfma(true, small, w, bias, big, g, s)) return;
   launch_conv_t_generic(small, w, bias, residual, big, g, s);
 }
-void launch_conv_wgrad(const float* big, const float* small, float* dW, float* db, ConvGeom g, PreOp pre,
+void launch_conv_wgrad(const float* big, const float* small, float* dW, float* db, ConvGeom g, PreOp pre, GradSlots sl,
                        hipStream_t s) {
   double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO, nw = (double)g.KH * g.KW * g.CI * g.CO;
   ProfScope ps(tagm(g.KH * g.KW == 1 ? "conv1x1_wgrad" : "convkxk_wgrad", (double)g.B * g.OH * g.OW), f4(nb + ns + nw), 2.0 * ns * g.KH * g.KW * g.CI, s);
-  if (launch_conv_wgrad_mfma(big, small, dW, db, g, pre, s)) return;
+  if (launch_conv_wgrad_mfma(big, small, dW, db, g, pre, sl, s)) return;
   launch_conv_wgrad_generic(big, small, dW, g, pre, s);
   if (db) launch_colsum(small, db, (int64_t)g.B * g.OH * g.OW, g.CO, s);
 }

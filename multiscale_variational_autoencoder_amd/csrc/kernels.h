@@ -42,12 +42,6 @@ void launch_conv_f(const float* big, const float* w, const float* bias, const fl
 void launch_conv_t(const float* small, const float* w, const float* bias, const float* residual, float* big,
                    ConvGeom g, hipStream_t s);
 // dW[kh,kw,ci,co] += sum pre(big) * small ; db[co] += sum small (db nullable)   (both pre-zeroed by the caller)
-void launch_conv_wgrad(const float* big, const float* small, float* dW, float* db, ConvGeom g, PreOp pre,
-                       hipStream_t s);
-// big = convT_1x1(small) and dot_out[b,c] = sum_hw big * dot_src, fused when the shape allows
-void launch_conv_t_dot(const float* small, const float* w, float* big, const float* dot_src, float* dot_out,
-                       ConvGeom g, hipStream_t s);
-// MobileNetV3 backward pair of a 1x1 C->C conv in one pass (kernels_mfma.hip: k_gemm_dual); false = not covered
 // Gradient slots: float atomics into a footprint of a few KB from hundreds of blocks run far below the chip's atomic
 // rate (MI355X_MICROARCH.md, Global float atomics: "contention"), so small weight gradients are accumulated into
 // n copies of the gradient arena (block b -> copy b % n) which k_slot_sum folds into the arena at the end of backward.
@@ -59,6 +53,12 @@ struct GradSlots {
   float* at(float* g) const { return (n && g) ? base + (g - gbase) : g; }
   int count() const { return n ? n : 1; }
 };
+void launch_conv_wgrad(const float* big, const float* small, float* dW, float* db, ConvGeom g, PreOp pre, GradSlots sl,
+                       hipStream_t s);
+// big = convT_1x1(small) and dot_out[b,c] = sum_hw big * dot_src, fused when the shape allows
+void launch_conv_t_dot(const float* small, const float* w, float* big, const float* dot_src, float* dot_out,
+                       ConvGeom g, hipStream_t s);
+// MobileNetV3 backward pair of a 1x1 C->C conv in one pass (kernels_mfma.hip: k_gemm_dual); false = not covered
 bool launch_gemm_dual_mfma(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
                            float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
                            GradSlots slots, hipStream_t s);

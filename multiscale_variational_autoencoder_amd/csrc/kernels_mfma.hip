@@ -337,7 +337,8 @@ bool launch_conv1x1_mfma(bool transposed, const float* in, const float* w, const
 template <int CI, int CO>
 __global__ void __launch_bounds__(256, 3) k_wgrad_rows(const float* __restrict__ big, const float* __restrict__ small,
                                                        float* __restrict__ dW, float* __restrict__ db, ConvGeom g,
-                                                       PreOp pre, int64_t M, int64_t rows_per_block) {
+                                                       PreOp pre, int64_t M, int64_t rows_per_block, int nslots,
+                                                       int64_t slot_stride) {
   constexpr int KT = CI / 32, NT = CO / 32;
   constexpr int R = 16;                          // rows per wave tile
   constexpr int CI4 = CI / 4, CO4 = CO / 4;
@@ -478,7 +479,8 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_rows(const float* __restrict__
     }
     __syncthreads();
   }
-  float* dWt = dW + (int64_t)tap * CI * CO;
+  const int64_t gslot = (int64_t)(blockIdx.x % nslots) * slot_stride;    // gradient slot (1x1 convs; kernels.h)
+  float* dWt = dW + gslot + (int64_t)tap * CI * CO;
   for (int idx = threadIdx.x; idx < CI * CO; idx += 256) atomicAdd(&dWt[idx], red[idx]);
   if (db != nullptr && tap == 0) {
     __syncthreads();
@@ -489,7 +491,7 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_rows(const float* __restrict__
       float t = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) t += red[q * CO + threadIdx.x];
-      atomicAdd(&db[threadIdx.x], t);
+      atomicAdd(&db[gslot + threadIdx.x], t);
     }
   }
 }
@@ -696,7 +698,7 @@ static bool run_wgrad_taprow(const float* big, const float* small, float* dW, fl
 
 template <int CI, int CO>
 static void run_wgrad_rows(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, PreOp pre,
-                           hipStream_t s) {
+                           GradSlots sl, hipStream_t s) {
   const int64_t M = (int64_t)g.B * g.OH * g.OW;
   const int taps = g.KH * g.KW;
   // ~768 blocks in total keeps every CU busy (3 resident blocks) while bounding the float-atomic traffic
@@ -706,17 +708,18 @@ static void run_wgrad_rows(const float* big, const float* small, float* dW, floa
   rpb = (rpb + 63) / 64 * 64;
   if (rpb < 64) rpb = 64;
   chunks = (M + rpb - 1) / rpb;
-  hipLaunchKernelGGL((k_wgrad_rows<CI, CO>), dim3((unsigned)chunks, taps), dim3(256), 0, s, big, small, dW, db, g, pre,
-                     M, rpb);
+  if (taps != 1) sl = GradSlots();                     // only the small 1x1 gradients are slotted (runtime: slot_chunks)
+  hipLaunchKernelGGL((k_wgrad_rows<CI, CO>), dim3((unsigned)chunks, taps), dim3(256), 0, s, big, small, sl.at(dW),
+                     sl.at(db), g, pre, M, rpb, sl.count(), sl.stride);
 }
 
-bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, PreOp pre,
+bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, PreOp pre, GradSlots sl,
                             hipStream_t s) {
   if (2 * g.OW < 64 / (g.CI / 4)) return false;        // the kernel's branch-free row stepping wraps at most twice
 #define MVAE_WG(A, B_)                                                          \
   if (g.CI == A && g.CO == B_) {                                                \
     if (!(g.KW == 5 && !pre.scale && !pre.gate && run_wgrad_taprow<A, B_>(big, small, dW, db, g, s)))  \
-      run_wgrad_rows<A, B_>(big, small, dW, db, g, pre, s);                     \
+      run_wgrad_rows<A, B_>(big, small, dW, db, g, pre, sl, s);                     \
     return true;                                                                \
   }
   MVAE_WG(64, 64) MVAE_WG(32, 32) MVAE_WG(64, 32) MVAE_WG(32, 64)

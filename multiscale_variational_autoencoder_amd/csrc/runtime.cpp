@@ -520,7 +520,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
     {
       hipStream_t w = wgrad_begin(h, sc, s);                                           // dout is ready on the chain
       PreOp gate{m.g, nullptr, nullptr};
-      launch_conv_wgrad(m.t1, dout, G + m.w2, G + m.b2, g, gate, w);                   // dW2 = (t1*g)^T dout, db2
+      launch_conv_wgrad(m.t1, dout, G + m.w2, G + m.b2, g, gate, h->gslots, w);                   // dW2 = (t1*g)^T dout, db2
       wgrad_reads(h, sc, dout, w);
     }
     launch_conv_t_dot(dout, P + m.w2, bufB, m.t1, dg, g, s);        // dt2 = dout . W2^T ; dg = sum_hw dt2 * t1
@@ -564,7 +564,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   if (!dual0) {
     {
       hipStream_t w = wgrad_begin(h, sc, s);                                           // dt0pre is ready on the chain
-      launch_conv_wgrad(x, bufC, G + m.w0, G + m.b0, g, none, w);
+      launch_conv_wgrad(x, bufC, G + m.w0, G + m.b0, g, none, h->gslots, w);
       wgrad_reads(h, sc, bufC, w);
     }
     launch_conv_t(bufC, P + m.w0, nullptr, dout, bufB, g, s);                          // da = dt0pre.W0^T + dout
@@ -987,7 +987,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     if (!fused_head) {
       launch_zero(sc.bn_sum_d, (int64_t)(sc.dc), s);
       launch_zero(sc.bn_sum_dx, (int64_t)(sc.dc), s);
-      launch_conv_wgrad(xbn, sc.dy, G + sc.out_w, G + sc.out_b, go, bn, s);
+      launch_conv_wgrad(xbn, sc.dy, G + sc.out_w, G + sc.out_b, go, bn, h->gslots, s);
       launch_conv_t(sc.dy, P + sc.out_w, nullptr, nullptr, d, go, s);
       launch_bn_bwd_reduce(d, xbn, sc.bn_mean, sc.bn_invstd, sc.bn_sum_d, sc.bn_sum_dx, M, sc.dc, s);
       launch_bn2d_bwd_apply(d, xbn, sc.bn_mean, sc.bn_invstd, P + sc.bn_g, sc.bn_sum_d, sc.bn_sum_dx, G + sc.bn_g,
@@ -1003,7 +1003,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
         ConvGeom g = blk.cg; g.B = B;
         {
           hipStream_t w = wgrad_begin(h, sc, s);
-          launch_conv_wgrad(d, prev, G + blk.cw, nullptr, g, none, w);
+          launch_conv_wgrad(d, prev, G + blk.cw, nullptr, g, none, h->gslots, w);
           if (!launch_colstat_opt(0, d, nullptr, 0, 0.f, h->gslots.at(G + blk.cb), h->gslots.count(), h->gslots.stride,
                                   (int64_t)B * g.IH * g.IW, g.CI, w))
             launch_colsum(d, G + blk.cb, (int64_t)B * g.IH * g.IW, g.CI, w);
@@ -1070,7 +1070,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
         ConvGeom g = blk.cg; g.B = B;
         {
           hipStream_t w = wgrad_begin(h, sc, s);
-          launch_conv_wgrad(prev, d, G + blk.cw, G + blk.cb, g, none, w);
+          launch_conv_wgrad(prev, d, G + blk.cw, G + blk.cb, g, none, h->gslots, w);
           wgrad_reads(h, sc, d, w);
         }
         float* n = acquire(h, sc, s);
@@ -1092,7 +1092,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       ConvGeom g{};
       g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
       g.KH = g.KW = 3; g.SH = g.SW = 1; g.PT = g.PL = 1;
-      launch_conv_wgrad(sc.band, d, G + sc.cb_w, G + sc.cb_b, g, none, s);
+      launch_conv_wgrad(sc.band, d, G + sc.cb_w, G + sc.cb_b, g, none, h->gslots, s);
     }
     release(sc, d);
   }
