@@ -61,7 +61,7 @@ void launch_conv_t_dot(const float* small, const float* w, float* big, const flo
 // MobileNetV3 backward pair of a 1x1 C->C conv in one pass (kernels_mfma.hip: k_gemm_dual); false = not covered
 bool launch_gemm_dual_mfma(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
                            float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
-                           GradSlots slots, hipStream_t s);
+                           GradSlots slots, int dslots, int64_t dstride, hipStream_t s);
 // ELU backward in place: d *= (y > 0 ? 1 : y + 1)
 void launch_elu_bwd(float* d, const float* y, int64_t n, hipStream_t s);
 
@@ -194,7 +194,7 @@ bool launch_se_forward(const float* gap, const float* W0, const float* b0, const
 bool launch_se_backward(const float* dg, const float* ulin, const float* xhat, const float* invstd, const float* gamma,
                         const float* beta, const float* s0, const float* gap, const float* W1, const float* W0,
                         float* ds1, float* dgap, float* dW1, float* db1, float* dgamma, float* dbeta, float* dW0,
-                        float* db0, float* part, int B, int C, GradSlots sl, hipStream_t s);
+                        float* db0, float* part, int B, int C, GradSlots sl, int dslots, int64_t dstride, hipStream_t s);
 int head_slots();
 // S: [head_slots()][2][dc] floats, zeroed by the caller; adds dW, db (gradient slots), dgamma, dbeta
 bool launch_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,

@@ -926,7 +926,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
                                                       const float* __restrict__ residual, float* __restrict__ Y,
                                                       float* __restrict__ dW, float* __restrict__ db,
                                                       float* __restrict__ dot_out, int64_t M, int64_t rows_per_image,
-                                                      int nslots, int64_t slot_stride) {
+                                                      int nslots, int64_t slot_stride, int dslots, int64_t dstride) {
+  // dot_out has `dslots` copies `dstride` floats apart (block b adds into copy b % dslots): with large feature maps
+  // thousands of tiles add into the 256 bytes of one image's gate gradient (C256-nb: 8192 adds per line, a ~200 us tail)
+  if (dot_out) dot_out += (int64_t)(blockIdx.x % dslots) * dstride;
   constexpr bool FAST = MODE != 0;
   constexpr int KH = C / 2, NT = C / 32, C4 = C / 4, MASK = C4 - 1;
   constexpr int WN = NT, WR = 4 / WN, TR = 32 * WR;        // block tile = TR rows
@@ -1153,14 +1156,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
 template <int C>
 static void run_gemm_dual(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
                           float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rpi, GradSlots sl,
-                          hipStream_t s) {
+                          int dslots, int64_t dstride, hipStream_t s) {
   constexpr int TR = 32 * (4 / (C / 32));
   int64_t ntiles = (M + TR - 1) / TR;
   const int cap = 2 * big_grid_cus();                      // 2 resident blocks per CU
   int grid = (int)(ntiles < cap ? ntiles : cap);
 #define MVAE_DUAL(MODE)                                                                                              \
   hipLaunchKernelGGL((k_gemm_dual<C, MODE>), dim3(grid), dim3(256), 0, s, X, W, aux, gate, residual, Y, sl.at(dW),   \
-                     sl.at(db), dot_out, M, rpi, sl.count(), sl.stride)
+                     sl.at(db), dot_out, M, rpi, sl.count(), sl.stride, dslots < 1 ? 1 : dslots, dstride)
   const bool full = M % TR == 0;
   if (full && gate && dot_out && !residual) MVAE_DUAL(1);
   else if (full && residual && !gate && !dot_out) MVAE_DUAL(2);
@@ -1171,10 +1174,10 @@ static void run_gemm_dual(const float* X, const float* W, const float* aux, cons
 // conv (1x1, C -> C) backward pair in one pass; false = shape not covered
 bool launch_gemm_dual_mfma(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
                            float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
-                           GradSlots sl, hipStream_t s) {
+                           GradSlots sl, int dslots, int64_t dstride, hipStream_t s) {
   if ((gate || dot_out) && (rows_per_image % 16) != 0) return false;
-  if (C == 64) { run_gemm_dual<64>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, sl, s); return true; }
-  if (C == 32) { run_gemm_dual<32>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, sl, s); return true; }
+  if (C == 64) { run_gemm_dual<64>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, sl, dslots, dstride, s); return true; }
+  if (C == 32) { run_gemm_dual<32>(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rows_per_image, sl, dslots, dstride, s); return true; }
   return false;
 }
 

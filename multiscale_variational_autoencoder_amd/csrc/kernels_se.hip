@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) k_se_bwd1(const float* __restrict__ dg, c
                                                  const float* __restrict__ beta, const float* __restrict__ W1,
                                                  float* __restrict__ ds1, float* __restrict__ dW1,
                                                  float* __restrict__ db1, float* __restrict__ part, int B, int RB,
-                                                 int nslots, int64_t slot_stride) {
+                                                 int nslots, int64_t slot_stride, int dslots, int64_t dstride) {
   constexpr int G = 256 / C, RPT = ROWS / G;
   __shared__ __attribute__((aligned(16))) float sV[ROWS * C];
   __shared__ __attribute__((aligned(16))) float sX[ROWS * C];
@@ -290,7 +290,9 @@ __global__ void __launch_bounds__(256) k_se_bwd1(const float* __restrict__ dg, c
   for (int q = 0; q < RPT; ++q) {
     const int r = rq + q * G;
     const int64_t o = (int64_t)(r0 + (r < nrows ? r : 0)) * C + j;
-    rdg[q] = dg[o]; rul[q] = ulin[o]; xh[q] = xhat[o];
+    float gsum = dg[o];                                   // the gate gradient arrives in `dslots` partial copies
+    for (int k = 1; k < dslots; ++k) gsum += dg[o + (int64_t)k * dstride];
+    rdg[q] = gsum; rul[q] = ulin[o]; xh[q] = xhat[o];
   }
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
@@ -433,12 +435,13 @@ bool launch_se_forward(const float* gap, const float* W0, const float* b0, const
 bool launch_se_backward(const float* dg, const float* ulin, const float* xhat, const float* invstd, const float* gamma,
                         const float* beta, const float* s0, const float* gap, const float* W1, const float* W0,
                         float* ds1, float* dgap, float* dW1, float* db1, float* dgamma, float* dbeta, float* dW0,
-                        float* db0, float* part, int B, int C, GradSlots sl, hipStream_t s) {
+                        float* db0, float* part, int B, int C, GradSlots sl, int dslots, int64_t dstride,
+                        hipStream_t s) {
   if ((C != 32 && C != 64) || B > 64 * kSeRowsMax) return false;
   const int RB = se_rows_per_block(B), nblk = (B + RB - 1) / RB;
   ProfScope ps("se_bwd", 4.0 * (8.0 * B * C + 2.0 * C * C), 8.0 * B * C * C, s);
   MVAE_SE_DISPATCH(k_se_bwd1, dg, ulin, xhat, gamma, beta, W1, ds1, sl.at(dW1), sl.at(db1), part, B, RB, sl.count(),
-                   sl.stride);
+                   sl.stride, dslots < 1 ? 1 : dslots, dstride);
   MVAE_SE_DISPATCH(k_se_bwd2, ds1, part, nblk, xhat, invstd, gamma, s0, gap, W0, dgap, sl.at(dW0), sl.at(db0), dgamma,
                    dbeta, B, RB, sl.count(), sl.stride);
   return true;

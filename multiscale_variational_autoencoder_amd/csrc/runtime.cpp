@@ -37,7 +37,7 @@ struct StateInfo { std::string name; int64_t elems, offset; float momentum; int6
 
 struct MN {
   int c = 0, H = 0, W = 0;
-  int seq = 0;                              // index of this block within its scale (slice of Scale::dg)
+  int dg_slots = 1, dg_prefix = 0;          // slot copies of this block's gate gradient, and where they start in Scale::dg
   int64_t w0, b0, wd, bd, sw0, sb0, gam, bet, sw1, sb1, w2, b2;
   int64_t st_mean, st_var;
   float *t0 = nullptr, *t1 = nullptr, *out = nullptr;
@@ -52,6 +52,7 @@ struct Block {
   MN mn;
 };
 struct Scale {
+  int dg_total = 0;                         // sum of the blocks' gate-gradient slot copies
   int nmn = 0;                              // MobileNetV3 blocks of this scale (encoder + decoder)
   int H, W, C, z, z_off;
   float *pcur = nullptr, *band = nullptr;
@@ -220,7 +221,15 @@ void build_mn(Builder& b, MN& m, const std::string& p, int c, int H, int W, Scal
   m.se_part = as_ptr(b.ws_alloc((int64_t)se_max_blocks(b.maxB) * 2 * c));
   if (hwc > sc.scratch_elems) sc.scratch_elems = hwc;
   if (c > sc.cmax) sc.cmax = c;
-  m.seq = sc.nmn++;
+  sc.nmn++;
+  // gate-gradient slot copies: one per 1024 pixels of a feature map (power of two, at most 64) when the fused
+  // squeeze-excite backward (which folds them) covers the shape
+  int ds = 1;
+  if ((c == 32 || c == 64) && b.maxB <= 4096)
+    while (ds < 64 && (int64_t)H * W / ds > 1024) ds *= 2;
+  m.dg_slots = ds;
+  m.dg_prefix = sc.dg_total;
+  sc.dg_total += ds;
 }
 
 int build_plan(mvae_handle* h) {
@@ -323,7 +332,7 @@ int build_plan(mvae_handle* h) {
     sc.dy = as_ptr(b.act("", hwC));
     for (int k = 0; k < 4; ++k) sc.scratch[k] = as_ptr(b.act("", sc.scratch_elems));
     int64_t cm = sc.cmax;
-    sc.dg = as_ptr(b.act("", cm * sc.nmn)); sc.dgap = as_ptr(b.act("", cm));   // dg: one [B, cmax] slice per block
+    sc.dg = as_ptr(b.act("", cm * sc.dg_total)); sc.dgap = as_ptr(b.act("", cm));   // dg: [B, cmax] per slot copy
     sc.ds1 = as_ptr(b.act("", cm)); sc.dv = as_ptr(b.act("", cm));
     sc.dw_part = as_ptr(b.ws_alloc((int64_t)kDwMaxBlocks * 10 * cm));
     sc.dz = as_ptr(b.act("", sc.z)); sc.dmu = as_ptr(b.act("", sc.z)); sc.dlv = as_ptr(b.act("", sc.z));
@@ -504,7 +513,8 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   const float* P = h->dp;
   float* G = h->dr;
   const int c = m.c;
-  float* dg = sc.dg + (int64_t)m.seq * B * sc.cmax;      // zeroed once per scale at the start of its backward chain
+  const int64_t dg_stride = (int64_t)B * sc.cmax;
+  float* dg = sc.dg + (int64_t)m.dg_prefix * dg_stride;  // zeroed once per scale at the start of its backward chain
   const int64_t HW = (int64_t)m.H * m.W;
   ConvGeom g = geom1x1(B, m.H, m.W, c, c);
   PreOp none{nullptr, nullptr, nullptr};
@@ -514,7 +524,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
     ProfScope ps(c == 64 ? "k_gemm_dual<64, 1>" : "k_gemm_dual<32, 1>", 12.0 * B * HW * c, 4.0 * B * HW * c * c, s);   // rocprof kernel names
     // dt2 = dout . W2^T ; dW2 += (t1*g)^T dout ; db2 ; dg = sum_hw dt2 * t1     -- one pass over (dout, t1)
     dual2 = launch_gemm_dual_mfma(dout, P + m.w2, m.t1, m.g, nullptr, bufB, G + m.w2, G + m.b2, dg, (int64_t)B * HW, HW,
-                                  c, h->gslots, s);
+                                  c, h->gslots, m.dg_slots, dg_stride, s);
   }
   if (!dual2) {
     {
@@ -528,7 +538,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   // squeeze-excite backward: dg -> (dW1, db1, dgamma, dbeta, dW0, db0) and dgap
   if (!launch_se_backward(dg, m.ulin, m.xhat, m.invstd, P + m.gam, P + m.bet, m.s0, m.gap, P + m.sw1, P + m.sw0, sc.ds1,
                           sc.dgap, G + m.sw1, G + m.sb1, G + m.gam, G + m.bet, G + m.sw0, G + m.sb0, m.se_part, B, c,
-                          h->gslots, s)) {
+                          h->gslots, m.dg_slots, dg_stride, s)) {
     {
       ProfScope ps("k_se_pair", 16.0 * B * c, 4.0 * B * c * c, s);
       // du = dg * hsig'(u):  dW1 += s1^T du, db1 += sum du  and  ds1 = du W1^T   (s1 = gamma*xhat + beta)
@@ -559,7 +569,7 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
     ProfScope ps(c == 64 ? "k_gemm_dual<64, 2>" : "k_gemm_dual<32, 2>", 16.0 * B * HW * c, 4.0 * B * HW * c * c, s);
     // da = dt0pre . W0^T + dout ; dW0 += a^T dt0pre ; db0     -- one pass over (dt0pre, a, dout)
     dual0 = launch_gemm_dual_mfma(bufC, P + m.w0, x, nullptr, dout, bufB, G + m.w0, G + m.b0, nullptr, (int64_t)B * HW, HW,
-                                  c, h->gslots, s);
+                                  c, h->gslots, 1, 0, s);
   }
   if (!dual0) {
     {
@@ -969,7 +979,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     profiler().cur_scale = si;
     Scale& sc = h->scales[si];
     for (int k = 0; k < 4; ++k) { sc.scratch_used[k] = false; sc.buf_pending[k] = false; }
-    launch_zero(sc.dg, (int64_t)sc.nmn * B * sc.cmax, s);        // squeeze-excite gate gradients of every block
+    launch_zero(sc.dg, (int64_t)sc.dg_total * B * sc.cmax, s);   // squeeze-excite gate gradients (all slot copies)
     const int64_t M = (int64_t)B * sc.H * sc.W;
     // ---- output conv + decoder BatchNorm
     const float* xbn = sc.dec.back().mn.out;
