@@ -204,9 +204,10 @@ bool launch_head_bwd(const float* x, const float* dy, const float* W, const floa
 bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* out, float* gap, int B, int H, int W,
                        int C, hipStream_t s);
 constexpr int kDwMaxBlocks = 1024;     // partial-sum scratch: kDwMaxBlocks * 10 * C floats
+// mask_in_lsb: dt2 carries the ReLU mask (t1 > 0) in its mantissa LSB (k_gemm_dual conv2 pair) and t1 is not read
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
-                         const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, int B, int H, int W, int C,
-                         hipStream_t s);
+                         const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
+                         int W, int C, hipStream_t s);
 // Dense layers around the latent (kernels_dense.hip); false = shape not covered
 bool launch_dense_mu_lv(const float* x, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
                         float* mu, float* lv, int B, int K, int Z, hipStream_t s);

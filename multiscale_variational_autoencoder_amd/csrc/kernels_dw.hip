@@ -123,6 +123,8 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const f32x4* __restrict__ i
   }
 }
 
+// LSB = the ReLU mask (t1 > 0) arrives in the mantissa LSB of dt2 (written by k_gemm_dual's conv2 pair): t1 is not read
+template <bool LSB>
 __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ dt2, const f32x4* __restrict__ t1,
                                                      const f32x4* __restrict__ t0, const f32x4* __restrict__ w,
                                                      const f32x4* __restrict__ gate, const f32x4* __restrict__ dgap,
@@ -166,7 +168,7 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
         const bool ok = t < row_items && x >= 0 && x < g.W;
         const int64_t o = ok ? ioff + ((int64_t)y * g.W + x) * g.C4 + c4 : 0;
         rd[u] = dt2[o];
-        ra[u] = t1[o];
+        if constexpr (!LSB) ra[u] = t1[o];
       }
     };
     auto store_row = [&](int y, const f32x4 (&rd)[3], const f32x4 (&ra)[3]) {   // d1 row y (+ halo) -> ring slot y & 3
@@ -178,7 +180,10 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
         if (t < row_items) {
           f32x4 v;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = (ok && ra[u][q] > 0.f) ? rd[u][q] * gg_c[q] + dg_c[q] : 0.f;
+          for (int q = 0; q < 4; ++q) {
+            const bool on = LSB ? (__float_as_uint(rd[u][q]) & 1u) != 0u : ra[u][q] > 0.f;
+            v[q] = (ok && on) ? rd[u][q] * gg_c[q] + dg_c[q] : 0.f;
+          }
           RING(y & 3, t / g.C4, c4) = v;
         }
       }
@@ -289,8 +294,8 @@ bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* o
 // fused backward through Multiply/GAP/ReLU + depthwise backward-data + depthwise weight/bias gradients.
 // `partial` is a scratch buffer of kDwMaxBlocks * 10 * C floats.
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
-                         const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, int B, int H, int W, int C,
-                         hipStream_t s) {
+                         const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
+                         int W, int C, hipStream_t s) {
   DwGeom g;
   size_t lds;
   if (!dw_geom(H, W, C, &g, &lds) || g.C4 > 64) return false;
@@ -305,9 +310,14 @@ bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, con
   int64_t work = (int64_t)B * nseg;
   int gy = (int)(work < kDwMaxBlocks / g.strips ? work : kDwMaxBlocks / g.strips);
   if (gy < 1) return false;
-  hipLaunchKernelGGL(k_dw_bwd_ring, dim3(g.strips, gy), dim3(256), lds, s, (const f32x4*)dt2, (const f32x4*)t1,
-                     (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0, sl.at(dW),
-                     sl.at(db), g, 1.0f / (float)(H * W), B, RS, nseg, sl.count(), sl.stride);
+  if (mask_in_lsb)
+    hipLaunchKernelGGL(k_dw_bwd_ring<true>, dim3(g.strips, gy), dim3(256), lds, s, (const f32x4*)dt2, (const f32x4*)t1,
+                       (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0, sl.at(dW),
+                       sl.at(db), g, 1.0f / (float)(H * W), B, RS, nseg, sl.count(), sl.stride);
+  else
+    hipLaunchKernelGGL(k_dw_bwd_ring<false>, dim3(g.strips, gy), dim3(256), lds, s, (const f32x4*)dt2, (const f32x4*)t1,
+                       (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0, sl.at(dW),
+                       sl.at(db), g, 1.0f / (float)(H * W), B, RS, nseg, sl.count(), sl.stride);
   return true;
 }
 

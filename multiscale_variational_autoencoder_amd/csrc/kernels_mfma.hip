@@ -1085,8 +1085,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
     for (int r = 0; r < 16; ++r) {
       const int rc = (r & 3) + 8 * (r >> 2);
       if (FAST || rc < lim) {
-        py[rc * C] = acc[r];
-        if (has_dot) dsum[r >> 3] += acc[r] * sA[SWZ1(rw * 32 + rc + 4 * h, n0 + i)];
+        if (has_dot) {
+          // conv2 pair: aux is t1 (the depthwise ReLU output).  The consumer of Y (k_dw_bwd_ring) needs Y and the ReLU
+          // mask t1 > 0 only: the mask rides in the mantissa LSB of Y (a perturbation of at most one ulp, 6e-8
+          // relative), which saves that kernel a whole pass over t1.
+          const float a = sA[SWZ1(rw * 32 + rc + 4 * h, n0 + i)];
+          dsum[r >> 3] += acc[r] * a;
+          py[rc * C] = __uint_as_float((__float_as_uint(acc[r]) & ~1u) | (a > 0.f ? 1u : 0u));
+        } else {
+          py[rc * C] = acc[r];
+        }
       }
     }
     if (has_dot) {

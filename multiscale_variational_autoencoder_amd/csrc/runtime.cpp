@@ -555,9 +555,10 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   float* bufC = acquire(h, sc, s);
   bool fused_dw;
   {
-    ProfScope ps("k_dw_bwd_ring", 16.0 * B * HW * c, 40.0 * B * HW * c, s);
-    fused_dw = launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC, G + m.wd, G + m.bd, h->gslots, B, m.H,
-                                   m.W, c, s);
+    ProfScope ps(dual2 ? "k_dw_bwd_ring<true>" : "k_dw_bwd_ring<false>", (dual2 ? 12.0 : 16.0) * B * HW * c,
+                 40.0 * B * HW * c, s);            // 3 passes when t1 is not read (mask in the LSB of dt2)
+    fused_dw = launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC, G + m.wd, G + m.bd, h->gslots, dual2, B,
+                                   m.H, m.W, c, s);
   }
   if (!fused_dw) {
     launch_mn_dt1pre(bufB, m.t1, m.g, sc.dgap, B, HW, c, 1.0f / (float)HW, s);
