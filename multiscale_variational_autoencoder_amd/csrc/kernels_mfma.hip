@@ -1179,6 +1179,106 @@ static void run_gemm_dual(const float* X, const float* W, const float* aux, cons
 #undef MVAE_DUAL
 }
 
+// =================================================================================================
+// conv0 of the MobileNetV3 block (1x1, C -> C, bias, ReLU; layer_blocks.py:594-602) in the dual kernel's tiling:
+// a 4-wave block shares ONE staged X tile (TR rows), a wave owns 32 rows x 32 output columns.  Against k_gemm_rows
+// (wave-private 32 x C tiles, 64 weight registers) this needs ~110 registers -> four blocks per CU instead of two, with
+// two tiles of prefetch each: the launch has a single input stream and was limited by bytes in flight (3.8 TB/s).
+// M % TR == 0; straight-line tile loop with the first pair of tiles peeled (counted vmcnt waits).
+// =================================================================================================
+template <int C>
+__global__ void __launch_bounds__(256, 4) k_conv0_tile(const float* __restrict__ X, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ Y, int64_t M) {
+  constexpr int KH = C / 2, NT = C / 32, C4 = C / 4, MASK = C4 - 1;
+  constexpr int WN = NT, WR = 4 / WN, TR = 32 * WR;
+  constexpr int LD = TR * C4 / 256;
+  __shared__ __attribute__((aligned(16))) float sX[TR * C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = wave % WN, rw = wave / WN, n0 = nw * 32;
+  const int i = lane & 31, h = lane >> 5;
+  float breg[KH];                                          // Wm[k = h*KH + t][n = n0 + i] = W[k*C + n]
+#pragma unroll
+  for (int t = 0; t < KH; ++t) breg[t] = W[(int64_t)(h * KH + t) * C + n0 + i];
+  const float bz = bias ? bias[n0 + i] : 0.f;
+  const int64_t ntiles = M / TR;
+  const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
+#define SWZ4(r, c4) ((r) * C4 + ((c4) ^ ((r) & MASK)))
+  struct Stage { f32x4 x[LD]; };
+  Stage S0, S1;
+  auto load_tile = [&](int64_t tile, Stage& S) {
+    const f32x4* px = X4 + tile * (TR * C4) + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < LD; ++j) S.x[j] = px[j * 256];
+  };
+  int64_t tile = blockIdx.x;
+  const int64_t g1 = gridDim.x, g2 = 2 * g1;
+  if (tile < ntiles) {
+    load_tile(tile, S0);
+    load_tile(tile + g1 < ntiles ? tile + g1 : tile, S1);
+  }
+  auto body = [&](int64_t tile, Stage& S) {
+    const int64_t row0 = tile * TR + rw * 32;
+    __syncthreads();                                       // previous tile's fragments are in registers everywhere
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+      const int idx = j * 256 + threadIdx.x;
+      reinterpret_cast<f32x4*>(sX)[SWZ4(idx / C4, idx % C4)] = S.x[j];
+    }
+    __syncthreads();
+    load_tile(tile + g2 < ntiles ? tile + g2 : tile, S);   // two tiles ahead, ahead of this tile's stores
+    __builtin_amdgcn_sched_barrier(0);                     // (the scheduler otherwise sinks these loads below the stores)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int QH = KH / 8 > 0 ? KH / 8 : 1, NB = (KH / 4) / QH;
+#pragma unroll
+    for (int bq = 0; bq < NB; ++bq) {
+      f32x4 afr[QH];
+#pragma unroll
+      for (int q = 0; q < QH; ++q)
+        afr[q] = reinterpret_cast<const f32x4*>(sX)[SWZ4(rw * 32 + i, h * (C4 / 2) + bq * QH + q)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < QH; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[(bq * QH + q) * 4 + e], acc, 0, 0, 0);
+    }
+    float* py = Y + (row0 + 4 * h) * C + n0 + i;           // accumulator layout: two 128-byte row segments per store
+#pragma unroll
+    for (int r = 0; r < 16; ++r) py[((r & 3) + 8 * (r >> 2)) * C] = fmaxf(acc[r] + bz, 0.f);
+  };
+  // This block's tiles are tile, tile + g1, ...: `mine` of them.  They are processed in pairs by a loop with a FIXED trip
+  // count and no exit in the middle (an early `break` between the two halves let LLVM sink the first half's prefetch
+  // below it -- behind the stores); the first pair is peeled (counted vmcnt waits), an odd last tile follows the loop.
+  const int64_t mine = tile < ntiles ? (ntiles - tile + g1 - 1) / g1 : 0;
+  if (mine >= 2) {
+    body(tile, S0);
+    body(tile + g1, S1);
+    tile += g2;
+    for (int64_t p = 1; p < mine / 2; ++p) {
+      body(tile, S0);
+      body(tile + g1, S1);
+      tile += g2;
+    }
+  }
+  if (mine & 1) body(tile, S0);
+#undef SWZ4
+}
+
+// Y = relu(X . W + b), C -> C; false = shape not covered (the caller uses k_gemm_rows)
+bool launch_conv0_tile(const float* X, const float* W, const float* bias, float* Y, int64_t M, int C, hipStream_t s) {
+  if (C != 64 && C != 32) return false;
+  const int TR = C == 64 ? 64 : 128;
+  if (M % TR != 0 || M < 256 * TR) return false;          // small launches: k_gemm_rows' wave-private tiles start faster
+  const int64_t ntiles = M / TR;
+  const int cap = 4 * big_grid_cus();                      // 4 resident blocks per CU
+  const int grid = (int)(ntiles < cap ? ntiles : cap);
+  if (C == 64) hipLaunchKernelGGL((k_conv0_tile<64>), dim3(grid), dim3(256), 0, s, X, W, bias, Y, M);
+  else hipLaunchKernelGGL((k_conv0_tile<32>), dim3(grid), dim3(256), 0, s, X, W, bias, Y, M);
+  return true;
+}
+
 // conv (1x1, C -> C) backward pair in one pass; false = shape not covered
 bool launch_gemm_dual_mfma(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
                            float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,

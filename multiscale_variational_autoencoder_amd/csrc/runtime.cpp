@@ -486,7 +486,12 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
   const int c = m.c;
   ConvGeom g = geom1x1(B, m.H, m.W, c, c);
   PreOp none{nullptr, nullptr, nullptr};
-  launch_conv_f(x, P + m.w0, P + m.b0, nullptr, m.t0, g, none, ACT_RELU, s);
+  bool tiled0;
+  {
+    ProfScope ps("k_conv0_tile", 8.0 * B * m.H * m.W * c, 2.0 * B * m.H * m.W * c * c, s);
+    tiled0 = launch_conv0_tile(x, P + m.w0, P + m.b0, m.t0, (int64_t)B * m.H * m.W, c, s);
+  }
+  if (!tiled0) launch_conv_f(x, P + m.w0, P + m.b0, nullptr, m.t0, g, none, ACT_RELU, s);
   bool fused_dw;
   {
     ProfScope ps("k_dw_fwd_ring<true>", 8.0 * B * m.H * m.W * c, 20.0 * B * m.H * m.W * c, s);
