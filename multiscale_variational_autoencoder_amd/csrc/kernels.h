@@ -195,8 +195,10 @@ bool launch_se_backward(const float* dg, const float* ulin, const float* xhat, c
                         const float* beta, const float* s0, const float* gap, const float* W1, const float* W0,
                         float* ds1, float* dgap, float* dW1, float* db1, float* dgamma, float* dbeta, float* dW0,
                         float* db0, float* part, int B, int C, GradSlots sl, int dslots, int64_t dstride, hipStream_t s);
-// conv0 of the MobileNetV3 block: Y = relu(X . W + b), C -> C (kernels_mfma.hip: k_conv0_tile); false = not covered
-bool launch_conv0_tile(const float* X, const float* W, const float* bias, float* Y, int64_t M, int C, hipStream_t s);
+// the MobileNetV3 block's 1x1 convs in the block-tiled form (kernels_mfma.hip: k_conv0_tile): conv0 Y = relu(X.W + b);
+// conv2 (gate != null) Y = (X * gate[image]).W + b + residual.  false = shape not covered
+bool launch_conv0_tile(const float* X, const float* W, const float* bias, const float* gate, const float* residual,
+                       float* Y, int64_t M, int64_t rows_per_image, int C, hipStream_t s);
 int head_slots();
 // S: [head_slots()][2][dc] floats, zeroed by the caller; adds dW, db (gradient slots), dgamma, dbeta
 bool launch_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,

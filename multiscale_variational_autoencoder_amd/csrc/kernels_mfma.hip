@@ -1186,12 +1186,19 @@ static void run_gemm_dual(const float* X, const float* W, const float* aux, cons
 // two tiles of prefetch each: the launch has a single input stream and was limited by bytes in flight (3.8 TB/s).
 // M % TR == 0; straight-line tile loop with the first pair of tiles peeled (counted vmcnt waits).
 // =================================================================================================
-template <int C>
-__global__ void __launch_bounds__(256, 4) k_conv0_tile(const float* __restrict__ X, const float* __restrict__ W,
-                                                       const float* __restrict__ bias, float* __restrict__ Y, int64_t M) {
+// GR = false: conv0 (bias + ReLU).  GR = true: conv2 of the block (layer_blocks.py:625-641): squeeze-excite gate folded
+// into the staged input, bias, residual add, no activation; rows_per_image % 16 == 0 (a thread's staged float4 j
+// belongs to rows 16j .. 16j+15 of the tile: one image), residual fetched one tile ahead in the accumulator layout.
+template <int C, bool GR>
+__global__ void __launch_bounds__(256, GR ? 2 : 4) k_conv0_tile(const float* __restrict__ X, const float* __restrict__ W,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ gate,
+                                                                const float* __restrict__ residual,
+                                                                float* __restrict__ Y, int64_t M, int64_t rows_per_image) {
   constexpr int KH = C / 2, NT = C / 32, C4 = C / 4, MASK = C4 - 1;
   constexpr int WN = NT, WR = 4 / WN, TR = 32 * WR;
   constexpr int LD = TR * C4 / 256;
+  static_assert(256 / C4 == 16 || !GR, "gated form: one staged float4 per 16-row group");
   __shared__ __attribute__((aligned(16))) float sX[TR * C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = wave % WN, rw = wave / WN, n0 = nw * 32;
@@ -1202,31 +1209,46 @@ __global__ void __launch_bounds__(256, 4) k_conv0_tile(const float* __restrict__
   const float bz = bias ? bias[n0 + i] : 0.f;
   const int64_t ntiles = M / TR;
   const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
+  const f32x4* G4 = reinterpret_cast<const f32x4*>(gate);
 #define SWZ4(r, c4) ((r) * C4 + ((c4) ^ ((r) & MASK)))
-  struct Stage { f32x4 x[LD]; };
+  struct Stage { f32x4 x[LD]; f32x4 g[GR ? LD : 1]; };
   Stage S0, S1;
   auto load_tile = [&](int64_t tile, Stage& S) {
     const f32x4* px = X4 + tile * (TR * C4) + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < LD; ++j) S.x[j] = px[j * 256];
+    if constexpr (GR) {
+#pragma unroll
+      for (int j = 0; j < LD; ++j)
+        S.g[j] = G4[((tile * TR + j * (256 / C4)) / rows_per_image) * C4 + threadIdx.x % C4];
+    }
+  };
+  float res[GR ? 16 : 1];
+  auto load_res = [&](int64_t tile) {
+    const float* pr = residual + (tile * TR + rw * 32 + 4 * h) * C + n0 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[GR ? r : 0] = pr[((r & 3) + 8 * (r >> 2)) * C];
   };
   int64_t tile = blockIdx.x;
   const int64_t g1 = gridDim.x, g2 = 2 * g1;
   if (tile < ntiles) {
     load_tile(tile, S0);
     load_tile(tile + g1 < ntiles ? tile + g1 : tile, S1);
+    if constexpr (GR) load_res(tile);
   }
-  auto body = [&](int64_t tile, Stage& S) {
+  auto body = [&](int64_t tile, Stage& S, int64_t next_res) {
     const int64_t row0 = tile * TR + rw * 32;
     __syncthreads();                                       // previous tile's fragments are in registers everywhere
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
       const int idx = j * 256 + threadIdx.x;
-      reinterpret_cast<f32x4*>(sX)[SWZ4(idx / C4, idx % C4)] = S.x[j];
+      f32x4 v = S.x[j];
+      if constexpr (GR) v = v * S.g[j];
+      reinterpret_cast<f32x4*>(sX)[SWZ4(idx / C4, idx % C4)] = v;
     }
     __syncthreads();
     load_tile(tile + g2 < ntiles ? tile + g2 : tile, S);   // two tiles ahead, ahead of this tile's stores
-    __builtin_amdgcn_sched_barrier(0);                     // (the scheduler otherwise sinks these loads below the stores)
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1245,37 +1267,53 @@ __global__ void __launch_bounds__(256, 4) k_conv0_tile(const float* __restrict__
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[(bq * QH + q) * 4 + e], acc, 0, 0, 0);
     }
     float* py = Y + (row0 + 4 * h) * C + n0 + i;           // accumulator layout: two 128-byte row segments per store
+    if constexpr (GR) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) py[((r & 3) + 8 * (r >> 2)) * C] = fmaxf(acc[r] + bz, 0.f);
+      for (int r = 0; r < 16; ++r) acc[r] += bz + res[r];
+      load_res(next_res);                                  // next tile's residual: requested BEFORE this tile's stores
+#pragma unroll
+      for (int r = 0; r < 16; ++r) py[((r & 3) + 8 * (r >> 2)) * C] = acc[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) py[((r & 3) + 8 * (r >> 2)) * C] = fmaxf(acc[r] + bz, 0.f);
+    }
   };
   // This block's tiles are tile, tile + g1, ...: `mine` of them.  They are processed in pairs by a loop with a FIXED trip
   // count and no exit in the middle (an early `break` between the two halves let LLVM sink the first half's prefetch
   // below it -- behind the stores); the first pair is peeled (counted vmcnt waits), an odd last tile follows the loop.
   const int64_t mine = tile < ntiles ? (ntiles - tile + g1 - 1) / g1 : 0;
+  const int64_t last = tile + (mine > 0 ? mine - 1 : 0) * g1;
+  auto nxt = [&](int64_t t) { return t + g1 <= last ? t + g1 : t; };
   if (mine >= 2) {
-    body(tile, S0);
-    body(tile + g1, S1);
+    body(tile, S0, tile + g1);
+    body(tile + g1, S1, nxt(tile + g1));
     tile += g2;
     for (int64_t p = 1; p < mine / 2; ++p) {
-      body(tile, S0);
-      body(tile + g1, S1);
+      body(tile, S0, tile + g1);
+      body(tile + g1, S1, nxt(tile + g1));
       tile += g2;
     }
   }
-  if (mine & 1) body(tile, S0);
+  if (mine & 1) body(tile, S0, tile);
 #undef SWZ4
 }
 
-// Y = relu(X . W + b), C -> C; false = shape not covered (the caller uses k_gemm_rows)
-bool launch_conv0_tile(const float* X, const float* W, const float* bias, float* Y, int64_t M, int C, hipStream_t s) {
+// conv0: Y = relu(X . W + b);  conv2 (gate != null): Y = (X * gate[image]) . W + b + residual.   C -> C.
+// false = shape not covered (the caller uses k_gemm_rows)
+bool launch_conv0_tile(const float* X, const float* W, const float* bias, const float* gate, const float* residual,
+                       float* Y, int64_t M, int64_t rows_per_image, int C, hipStream_t s) {
   if (C != 64 && C != 32) return false;
   const int TR = C == 64 ? 64 : 128;
   if (M % TR != 0 || M < 256 * TR) return false;          // small launches: k_gemm_rows' wave-private tiles start faster
+  const bool gr = gate != nullptr;
+  if (gr && (C != 64 || !residual || rows_per_image % 16 != 0)) return false;
+  if (!gr && residual) return false;
   const int64_t ntiles = M / TR;
-  const int cap = 4 * big_grid_cus();                      // 4 resident blocks per CU
+  const int cap = (gr ? 2 : 4) * big_grid_cus();           // resident blocks per CU (the gated form needs > 168 registers)
   const int grid = (int)(ntiles < cap ? ntiles : cap);
-  if (C == 64) hipLaunchKernelGGL((k_conv0_tile<64>), dim3(grid), dim3(256), 0, s, X, W, bias, Y, M);
-  else hipLaunchKernelGGL((k_conv0_tile<32>), dim3(grid), dim3(256), 0, s, X, W, bias, Y, M);
+  if (gr) hipLaunchKernelGGL((k_conv0_tile<64, true>), dim3(grid), dim3(256), 0, s, X, W, bias, gate, residual, Y, M, rows_per_image);
+  else if (C == 64) hipLaunchKernelGGL((k_conv0_tile<64, false>), dim3(grid), dim3(256), 0, s, X, W, bias, gate, residual, Y, M, rows_per_image);
+  else hipLaunchKernelGGL((k_conv0_tile<32, false>), dim3(grid), dim3(256), 0, s, X, W, bias, gate, residual, Y, M, rows_per_image);
   return true;
 }
 

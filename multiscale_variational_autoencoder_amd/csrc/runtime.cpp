@@ -489,7 +489,7 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
   bool tiled0;
   {
     ProfScope ps("k_conv0_tile", 8.0 * B * m.H * m.W * c, 2.0 * B * m.H * m.W * c * c, s);
-    tiled0 = launch_conv0_tile(x, P + m.w0, P + m.b0, m.t0, (int64_t)B * m.H * m.W, c, s);
+    tiled0 = launch_conv0_tile(x, P + m.w0, P + m.b0, nullptr, nullptr, m.t0, (int64_t)B * m.H * m.W, (int64_t)m.H * m.W, c, s);
   }
   if (!tiled0) launch_conv_f(x, P + m.w0, P + m.b0, nullptr, m.t0, g, none, ACT_RELU, s);
   bool fused_dw;
@@ -509,8 +509,15 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
                     stats + m.st_mean, stats + m.st_var, B, c, kSeBnEps, training ? 1 : 0, s);
     launch_gemm_nn(m.s1, P + m.sw1, P + m.sb1, m.g, m.ulin, B, c, c, ACT_HSIG, s);
   }
-  PreOp gate{m.g, nullptr, nullptr};
-  launch_conv_f(m.t1, P + m.w2, P + m.b2, x, m.out, g, gate, ACT_NONE, s);
+  bool tiled2;
+  {
+    ProfScope ps("k_conv2_tile", 12.0 * B * m.H * m.W * c, 2.0 * B * m.H * m.W * c * c, s);
+    tiled2 = launch_conv0_tile(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, (int64_t)B * m.H * m.W, (int64_t)m.H * m.W, c, s);
+  }
+  if (!tiled2) {
+    PreOp gate{m.g, nullptr, nullptr};
+    launch_conv_f(m.t1, P + m.w2, P + m.b2, x, m.out, g, gate, ACT_NONE, s);
+  }
 }
 
 // returns the buffer holding d(loss)/d(block input); consumes (releases) `dout` when it is a pool buffer
