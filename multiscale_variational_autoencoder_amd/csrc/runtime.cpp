@@ -28,7 +28,8 @@ constexpr float kSeBnMomentum = 0.99f, kSeBnEps = 1e-3f;     // keras BatchNorma
 constexpr float kDecBnMomentum = 0.999f, kDecBnEps = 1e-4f;  // multiscale_vae.py:420-421
 constexpr int kGradSlots = 16;
 constexpr int64_t kAlign = 64;            // floats; every tensor / buffer starts on a 256-byte line
-constexpr int kChunk = 8192;
+constexpr int kChunk = 2048;               // optimiser work item: one block per chunk (small chunks = enough blocks in flight)
+constexpr int kSlotMaxElems = 8192;       // tensors up to this size accumulate through the gradient slots
 
 std::string g_create_error;
 
@@ -365,7 +366,7 @@ int build_plan(mvae_handle* h) {
     }
   }
   for (const ChunkDesc& cd : h->chunks)
-    if (h->params[cd.tensor].elems <= kChunk) h->slot_chunks.push_back(cd);
+    if (h->params[cd.tensor].elems <= kSlotMaxElems) h->slot_chunks.push_back(cd);
   for (const StateInfo& s : h->states) {
     StateDesc sd;
     sd.offset = s.offset; sd.len = (int32_t)s.elems; sd.momentum = s.momentum;
