@@ -741,16 +741,32 @@ bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, flo
 // channels straight from global memory (L2-resident re-reads across taps), the tap's KC x NC weight slice is
 // double-buffered in LDS for the whole block.
 // =================================================================================================
-template <int KC, int NC, bool TFORM>
-__global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in, const float* __restrict__ W,
-                                                   const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// fp32 MFMAs share the SIMD's issue slots with ordinary VALU work: measured (tools/mfma_mix.hip) every VALU instruction
+// next to v_mfma_f32_32x32x2_f32 costs the MFMA 2.5 - 5 cycles, with any number of waves per SIMD.  The first version
+// of this kernel spent ~300 VALU instructions per tap (address arithmetic, padding selects, 64-bit pointers) next to
+// its 32 MFMAs and ran at 85 TFLOP/s of 155.  So the tap loop is written to need almost none:
+//   * input pixels come through a raw buffer resource: address = 32-bit byte offset, and a tap that falls into the SAME
+//     padding gets bit 31 of its offset set -- out of range for the buffer, which returns zeros (no selects, no masks
+//     on the data).  Per slot and tap: and, compare, select, add.
+//   * every lane fetches whole rows (CPP = KC/4 lanes x 16 B cover one pixel) and the wave turns them into MFMA A
+//     fragments (lane = pixel) through a wave-private, XOR-swizzled LDS tile; LDS addresses are loop constants.
+//   * WB = 1 keeps ONE weight slice in LDS (two barriers per tap): 40 KB per block, 4 blocks = 16 waves per CU, which is
+//     what the 1024-block launches of the headline batch need to run as a single round.
+template <int KC, int NC, bool TFORM, int WB>
+__global__ void __launch_bounds__(256, WB == 1 ? 4 : 2)
+k_conv_taps(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
+            float* __restrict__ out, ConvGeom g, unsigned in_bytes, unsigned out_bytes, int dbg) {
   constexpr int KHF = KC / 2, NT = NC / 32, Q = KHF / 4;
   // T-form stages W[tap][n][k] transposed (consecutive threads -> consecutive k): a row pitch of NC + 1 keeps those
   // stores conflict-free (pitch NC put all 32 lanes of a store on one bank: 85 % of the kernel's LDS cycles were bank
   // conflicts); the fragment reads (lanes along n) are conflict-free for either pitch
   constexpr int WP = TFORM ? NC + 1 : NC;
-  __shared__ __attribute__((aligned(16))) float sW[2][KC * WP];
-  __shared__ int64_t sOff[4][32];
+  constexpr int CPP = KC / 4, PPI = 64 / CPP, SWZ = KC == 32 ? 1 : 0;
+  static_assert(32 / PPI == Q, "one load slot per fragment quad");
+  __shared__ __attribute__((aligned(16))) float sW[WB][KC * WP];
+  __shared__ __attribute__((aligned(16))) float sA[4][32 * KC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   // ---- which output pixels
@@ -759,25 +775,59 @@ __global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in,
     py = blockIdx.y / g.SW; px = blockIdx.y % g.SW;
     CH = (g.IH - py + g.SH - 1) / g.SH; CW = (g.IW - px + g.SW - 1) / g.SW;
   }
-  const int64_t Mc = (int64_t)g.B * CH * CW;
-  const int64_t p0 = (int64_t)blockIdx.x * 128;
+  const unsigned Mc = (unsigned)(g.B * CH * CW);           // < 2^31 (launcher)
+  const unsigned p0 = blockIdx.x * 128u;
   if (p0 >= Mc) return;                         // block-uniform
-  const int64_t p = p0 + wave * 32 + i;
-  const bool pvalid = p < Mc;
-  int cx = 0, cy = 0;
-  int64_t b = 0;
-  if (pvalid) { cx = (int)(p % CW); int64_t q = p / CW; cy = (int)(q % CH); b = q / CH; }
-  if (h == 0) {
-    int64_t off = -1;
-    if (pvalid) off = TFORM ? (((b * g.IH + (cy * g.SH + py)) * g.IW + (cx * g.SW + px)) * NC) : p * NC;
-    sOff[wave][i] = off;
-  }
+  const int SHh = TFORM ? g.OH : g.IH, SWw = TFORM ? g.OW : g.IW;      // the tensor the taps read
   // ---- tap list (block-uniform)
   int kh0 = 0, kw0 = 0, khs = 1, kws = 1;
   if (TFORM) { kh0 = (py + g.PT) % g.SH; kw0 = (px + g.PL) % g.SW; khs = g.SH; kws = g.SW; }
-  const int nkh = kh0 < g.KH ? (g.KH - kh0 + khs - 1) / khs : 0;
+  const int nkh = kh0 < g.KH ? (g.KH - kh0 + khs - 1) / khs : 0;      // <= 8 (launcher)
   const int nkw = kw0 < g.KW ? (g.KW - kw0 + kws - 1) / kws : 0;
-  const int ntaps = nkh * nkw;
+  int ntaps = nkh * nkw;
+  if ((dbg >> 8) && ntaps > (dbg >> 8)) ntaps = dbg >> 8;
+  // ---- the pixels this lane FETCHES: slot j = pixel lp + PPI * j of the wave, 16-byte chunk ch.
+  // base[j] = byte offset of (window origin pixel, chunk); inv[j] bit t = tap row t leaves the image, bit 8 + t = tap
+  // column t does
+  const int lp = lane / CPP, ch = lane % CPP;
+  unsigned base[Q], inv[Q];
+  const bool pow2 = (CW & (CW - 1)) == 0 && (CH & (CH - 1)) == 0;       // block-uniform: shifts instead of divisions
+  const int lgw = 31 - __builtin_clz((unsigned)CW), lgh = 31 - __builtin_clz((unsigned)CH);
+  auto split = [&](unsigned p, int& cx, int& cy, int& b) {
+    if (pow2) { cx = (int)(p & (unsigned)(CW - 1)); cy = (int)((p >> lgw) & (unsigned)(CH - 1)); b = (int)(p >> (lgw + lgh)); }
+    else { cx = (int)(p % (unsigned)CW); const unsigned q = p / (unsigned)CW; cy = (int)(q % (unsigned)CH); b = (int)(q / (unsigned)CH); }
+  };
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    const unsigned p = p0 + wave * 32 + lp + PPI * j;
+    int cx, cy, b;
+    split(p < Mc ? p : 0u, cx, cy, b);
+    const int y0 = TFORM ? cy : cy * g.SH, x0 = TFORM ? cx : cx * g.SW;
+    base[j] = (unsigned)(((b * SHh + y0) * SWw + x0) * KC + ch * 4) * 4u;
+    inv[j] = p < Mc ? (unsigned)(y0 << 16 | x0) : 0xFFFFFFFFu;           // coordinates for now, masks below
+  }
+  {
+    unsigned m[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) m[j] = inv[j] == 0xFFFFFFFFu ? 0xFFFFu : 0u;
+    for (int t = 0; t < nkh; ++t) {                                      // run-time trip counts: scalar loops
+      const int kh = kh0 + t * khs;
+      const int dy = TFORM ? (py + g.PT - kh) / g.SH : kh - g.PT;        // T: exact, kh is in this phase's residue class
+#pragma unroll
+      for (int j = 0; j < Q; ++j)
+        if ((unsigned)((int)(inv[j] >> 16) + dy) >= (unsigned)SHh) m[j] |= 1u << t;
+    }
+    for (int t = 0; t < nkw; ++t) {
+      const int kw = kw0 + t * kws;
+      const int dx = TFORM ? (px + g.PL - kw) / g.SW : kw - g.PL;
+#pragma unroll
+      for (int j = 0; j < Q; ++j)
+        if ((unsigned)((int)(inv[j] & 0xFFFFu) + dx) >= (unsigned)SWw) m[j] |= 0x100u << t;
+    }
+#pragma unroll
+    for (int j = 0; j < Q; ++j) inv[j] = m[j];
+  }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00020000);
 
   f32x16 acc[NT];
 #pragma unroll
@@ -785,69 +835,96 @@ __global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in,
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-  // The next tap's weight slice travels global -> registers (issued BEFORE this tap's MFMAs) -> LDS (written AFTER
-  // them): the L2 latency of the weight loads hides under the MFMAs instead of stalling them at an LDS write.
+  // The next tap's weight slice and input pixels travel global -> registers (issued BEFORE this tap's MFMAs) -> LDS
+  // (written AFTER them): their latency hides under the MFMAs instead of stalling them at an LDS write.
   constexpr int WPT = KC * NC / 256;                     // weights per thread per tap
   float wtmp[WPT];
-  auto fetch_w = [&](int it) {
-    const int kh = kh0 + (it / nkw) * khs, kw = kw0 + (it % nkw) * kws;
+  auto fetch_w = [&](int th, int tw) {
+    const int kh = kh0 + th * khs, kw = kw0 + tw * kws;
     const float* wt = W + (int64_t)(kh * g.KW + kw) * KC * NC;
+    if (TFORM) {
 #pragma unroll
-    for (int u = 0; u < WPT; ++u) wtmp[u] = wt[threadIdx.x + u * 256];
+      for (int u = 0; u < WPT; ++u) wtmp[u] = wt[threadIdx.x + u * 256];
+    } else {                                             // F-form copies the slice as it lies: 16 B per lane
+#pragma unroll
+      for (int u = 0; u < WPT / 4; ++u) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wt + (threadIdx.x + u * 256) * 4);
+        wtmp[u * 4] = v[0]; wtmp[u * 4 + 1] = v[1]; wtmp[u * 4 + 2] = v[2]; wtmp[u * 4 + 3] = v[3];
+      }
+    }
   };
   auto store_w = [&](int buf) {
+    if (TFORM) {
 #pragma unroll
-    for (int u = 0; u < WPT; ++u) {
-      const int idx = threadIdx.x + u * 256;
-      // sW[k][n]; F: W[tap][k][n] as stored; T: W[tap][n][k]
-      if (TFORM) { int n = idx / KC, k = idx % KC; sW[buf][k * WP + n] = wtmp[u]; }
-      else sW[buf][idx] = wtmp[u];
+      for (int u = 0; u < WPT; ++u) {
+        const int idx = threadIdx.x + u * 256;           // W[tap][n][k] -> sW[k][n]
+        const int n = idx / KC, k = idx % KC;
+        sW[buf][k * WP + n] = wtmp[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < WPT / 4; ++u)
+        *reinterpret_cast<f32x4*>(&sW[buf][(threadIdx.x + u * 256) * 4]) =
+            f32x4{wtmp[u * 4], wtmp[u * 4 + 1], wtmp[u * 4 + 2], wtmp[u * 4 + 3]};
     }
   };
-  f32x4 a_next[Q];
-  auto load_a = [&](int it) {
-    const int kh = kh0 + (it / nkw) * khs, kw = kw0 + (it % nkw) * kws;
-    int yy, xx;
-    bool ok = pvalid;
-    if (TFORM) {
-      yy = cy + (py + g.PT - kh) / g.SH;          // exact: kh is in this phase's residue class
-      xx = cx + (px + g.PL - kw) / g.SW;
-      ok = ok && yy >= 0 && yy < g.OH && xx >= 0 && xx < g.OW;
-    } else {
-      yy = cy * g.SH + kh - g.PT;
-      xx = cx * g.SW + kw - g.PL;
-      ok = ok && yy >= 0 && yy < g.IH && xx >= 0 && xx < g.IW;
-    }
-    const int SHh = TFORM ? g.OH : g.IH, SWw = TFORM ? g.OW : g.IW;
-    const f32x4* src = reinterpret_cast<const f32x4*>(in + ((b * SHh + yy) * SWw + xx) * KC + h * KHF);
+  u32x4 atmp[Q];
+  auto fetch_a = [&](int th, int tw) {
+    const int kh = kh0 + th * khs, kw = kw0 + tw * kws;
+    const int dy = TFORM ? (py + g.PT - kh) / g.SH : kh - g.PT;
+    const int dx = TFORM ? (px + g.PL - kw) / g.SW : kw - g.PL;
+    const unsigned delta = (dbg & 1) ? 0u : (unsigned)((dy * SWw + dx) * KC * 4);
+    const unsigned sel = (1u << th) | (0x100u << tw);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      a_next[q] = ok ? src[q] : z;
+    for (int j = 0; j < Q; ++j) {
+      const unsigned off = (inv[j] & sel) ? 0x80000000u : base[j] + delta;
+      atmp[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    }
+  };
+  float* myA = sA[wave];
+  auto store_a = [&]() {
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const int pl = lp + PPI * j;
+      *reinterpret_cast<u32x4*>(myA + pl * KC + ((ch ^ ((pl >> SWZ) & (CPP - 1))) * 4)) = atmp[j];
     }
   };
 
-  if (ntaps > 0) { fetch_w(0); load_a(0); store_w(0); }
+  if (ntaps > 0) { fetch_w(0, 0); fetch_a(0, 0); store_w(0); store_a(); }
+  int th = 0, tw = 0;                     // the NEXT tap's row / column in the tap list
   for (int it = 0; it < ntaps; ++it) {
-    __syncthreads();       // sW[it & 1] is complete; every wave has finished reading sW[(it + 1) & 1]
-    f32x4 a[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) a[q] = a_next[q];
+    if (!(dbg & 8)) __syncthreads();       // sW[it % WB] and sA are complete (WB = 2: and sW[(it + 1) & 1] is free)
     const bool more = it + 1 < ntaps;
-    if (more) { fetch_w(it + 1); load_a(it + 1); }
+    if (++tw == nkw) { tw = 0; ++th; }
+    if (more) { if (!(dbg & 4)) fetch_w(th, tw); if (!(dbg & 2)) fetch_a(th, tw); }
     __builtin_amdgcn_sched_barrier(0);
-    const float* w = sW[it & 1];
+    const float* w = sW[WB == 2 ? (it & 1) : 0];
+    // A and B fragments one group of 4 k-steps ahead of the MFMAs that use them
+    f32x4 af[2];
+    float bw[2][4][NT];
+    auto load_ab = [&](int q, int slot) {
+      af[slot] = *reinterpret_cast<const f32x4*>(myA + i * KC + (((h * Q + q) ^ ((i >> SWZ) & (CPP - 1))) * 4));
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = h * KHF + q * 4 + e;
+        for (int nt = 0; nt < NT; ++nt) bw[slot][e][nt] = w[(h * KHF + q * 4 + e) * WP + nt * 32 + i];
+    };
+    load_ab(0, 0);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (q + 1 < Q) load_ab(q + 1, (q + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], w[k * WP + nt * 32 + i], acc[nt], 0, 0, 0);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) store_w((it + 1) & 1);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][e], bw[q & 1][e][nt], acc[nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // sA is wave-private and this wave's fragment reads of it are done (their data fed the MFMAs above); a single
+    // weight buffer must wait until every wave is through with it
+    if (WB == 1 && more) __syncthreads();
+    if (more) { if (!(dbg & 4)) store_w(WB == 2 ? ((it + 1) & 1) : 0); if (!(dbg & 16)) store_a(); }
   }
   // epilogue: the bias comes from an UNCONDITIONAL load and the 16 row offsets are read from LDS up front.  With the
   // bias load inside `if (bias)`, every exec-masked store block below carried its own s_waitcnt vmcnt(0) -- i.e. each of
@@ -855,17 +932,34 @@ __global__ void __launch_bounds__(256) k_conv_taps(const float* __restrict__ in,
   float bv[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias ? bias : W)[nt * 32 + i];
-  __syncthreads();     // sOff visible (also when ntaps == 0)
-  int64_t offs[16];
+  // byte offsets of the wave's 32 output pixels, through the (now idle) wave-private A tile; pixels past the end get
+  // bit 31, which the buffer store drops
+  unsigned* sOff = reinterpret_cast<unsigned*>(myA);
+  __builtin_amdgcn_wave_barrier();
+  if (h == 0) {
+    const unsigned p = p0 + wave * 32 + i;
+    unsigned off = 0x80000000u;
+    if (p < Mc) {
+      int cx, cy, b;
+      split(p, cx, cy, b);
+      off = (TFORM ? (unsigned)(((b * g.IH + (cy * g.SH + py)) * g.IW + (cx * g.SW + px)) * NC) : p * NC) * 4u;
+    }
+    sOff[i] = off;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  unsigned offs[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) offs[r] = sOff[wave][(r & 3) + 8 * (r >> 2) + 4 * h];
+  for (int r = 0; r < 16; ++r) offs[r] = sOff[(r & 3) + 8 * (r >> 2) + 4 * h];
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)out_bytes, 0x00020000);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 32 + i;
+    const unsigned n4 = (unsigned)(nt * 32 + i) * 4u;
     const float b = bias ? bv[nt] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      if (offs[r] >= 0) out[offs[r] + n] = acc[nt][r] + b;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[nt][r] + b), orsrc, offs[r] + n4, 0, 0);
   }
 }
 
@@ -880,13 +974,27 @@ static void run_conv_taps(const float* in, const float* W, const float* bias, fl
   } else {
     Mc = (int64_t)g.B * g.OH * g.OW;
   }
-  hipLaunchKernelGGL((k_conv_taps<KC, NC, TFORM>), dim3((unsigned)((Mc + 127) / 128), classes), dim3(256), 0, s, in, W,
-                     bias, out, g);
+  const unsigned in_bytes = (unsigned)((int64_t)g.B * (TFORM ? g.OH * g.OW : g.IH * g.IW) * KC * 4);
+  const int dbg = getenv("MVAE_DBG_SAMEPIX") ? atoi(getenv("MVAE_DBG_SAMEPIX")) : 0;
+  const dim3 grid((unsigned)((Mc + 127) / 128), classes);
+  const unsigned out_bytes = (unsigned)((int64_t)g.B * (TFORM ? g.IH * g.IW : g.OH * g.OW) * NC * 4);
+  // one weight buffer where that is what brings the block down to 40 KB of LDS (4 blocks per CU), two otherwise
+  constexpr int WP = TFORM ? NC + 1 : NC;
+  constexpr bool kOneBuf = (2 * KC * WP + 4 * 32 * KC) * 4 > 40 * 1024 && (KC * WP + 4 * 32 * KC) * 4 <= 40 * 1024;
+  if (kOneBuf && !(dbg & 32))
+    hipLaunchKernelGGL((k_conv_taps<KC, NC, TFORM, kOneBuf ? 1 : 2>), grid, dim3(256), 0, s, in, W, bias, out, g, in_bytes,
+                       out_bytes, dbg);
+  else
+    hipLaunchKernelGGL((k_conv_taps<KC, NC, TFORM, 2>), grid, dim3(256), 0, s, in, W, bias, out, g, in_bytes, out_bytes, dbg);
 }
 
 bool launch_conv_taps_mfma(bool transposed, const float* in, const float* w, const float* bias, float* out,
                            const ConvGeom& g, hipStream_t s) {
   const int KC = transposed ? g.CO : g.CI, NC = transposed ? g.CI : g.CO;
+  // the kernel indexes pixels with 32-bit integers
+  // the kernel addresses its input with 31-bit byte offsets and lists at most 8 tap rows / columns per phase
+  if ((int64_t)g.B * g.IH * g.IW * g.CI * 4 >= (1LL << 31) || (int64_t)g.B * g.OH * g.OW * g.CO * 4 >= (1LL << 31)) return false;
+  if (g.KH > 8 || g.KW > 8) return false;
 #define MVAE_CT(A, B_)                                                              \
   if (KC == A && NC == B_) {                                                        \
     if (transposed) run_conv_taps<A, B_, true>(in, w, bias, out, g, s);             \
