@@ -14,6 +14,8 @@
 // contiguous run of floats (16-byte LDS reads).
 #include "kernels.h"
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 namespace mvae {
 
 // Blocks of the persistent (grid-stride) kernels: two register-limited workgroups per CU on `big_grid_cus()` CUs.
@@ -534,23 +536,38 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_taprow(const float* __restrict
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
 
-  const int64_t m_begin = (int64_t)blockIdx.x * rows_per_block;
-  int64_t m_end = m_begin + rows_per_block;
-  if (m_end > M) m_end = M;
+  // M < 2^31 (launcher): rows are 32-bit
+  const uint32_t m_begin = blockIdx.x * (uint32_t)rows_per_block;
+  uint32_t m_end = m_begin + (uint32_t)rows_per_block;
+  if (m_end > (uint32_t)M) m_end = (uint32_t)M;
 
-  // raw, clamped prefetch loads; masks applied at the LDS write (see k_wgrad_rows)
-  f32x4 px[LX], pg[LG];
-  float pm[LX];
-  int pb[LX], poh[LX], pow_[LX];                  // decoded (b, oh, ow) of this lane's rows in the current tile
-  auto decode_tile = [&](int64_t row0) {
-    const uint32_t m = (uint32_t)(row0 + xr);     // M < 2^31 (checked by the launcher): 32-bit divisions
-    uint32_t b = m / (uint32_t)HWo;
-    uint32_t rem = m - b * (uint32_t)HWo;
-    int oh = (int)(rem / (uint32_t)g.OW), ow = (int)(rem - (uint32_t)oh * (uint32_t)g.OW);
-    int bi = (int)b;
+  // Both operands come through raw buffer resources with 32-bit byte offsets: a row past the block's range or a tap
+  // in the SAME padding gets an offset >= 2^31, out of range for the buffer, which returns zeros -- no masks or
+  // multiplies on the data, ~4 VALU instructions per 16-byte load (fp32 MFMAs share their issue slots with VALU work,
+  // see k_conv_taps: the first version's ~110 VALU instructions per 16 MFMAs held it at 70 - 83 TFLOP/s).
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(big), 0,
+      (int)((unsigned)g.B * g.IH * g.IW * CI * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(small), 0,
+      (int)((unsigned)M * CO * 4u), 0x00020000);
+  u32x4 px[LX], pg[LG];
+  unsigned pbase[LX];                  // byte offset of (row kh of the window, column -PL, chunk) per slot; >= 2^31: no row
+  int px0[LX];                         // input column of tap kw = 0
+  const bool pow2 = (g.OW & (g.OW - 1)) == 0 && (g.OH & (g.OH - 1)) == 0;      // block-uniform
+  const int lgw = 31 - __builtin_clz((unsigned)g.OW), lgh = 31 - __builtin_clz((unsigned)g.OH);
+  auto decode_tile = [&](uint32_t row0) {
+    const uint32_t m = row0 + xr;
+    int bi, oh, ow;
+    if (pow2) { ow = (int)(m & (uint32_t)(g.OW - 1)); oh = (int)((m >> lgw) & (uint32_t)(g.OH - 1)); bi = (int)(m >> (lgw + lgh)); }
+    else {
+      const uint32_t b = m / (uint32_t)HWo, rem = m - b * (uint32_t)HWo;
+      oh = (int)(rem / (uint32_t)g.OW); ow = (int)(rem - (uint32_t)oh * (uint32_t)g.OW); bi = (int)b;
+    }
 #pragma unroll
     for (int j = 0; j < LX; ++j) {
-      pb[j] = bi; poh[j] = oh; pow_[j] = ow;
+      const int yy = oh * g.SH + kh - g.PT, x0 = ow * g.SW - g.PL;
+      const bool ok = (row0 + xr + j * RPX < m_end) && (unsigned)yy < (unsigned)g.IH;
+      pbase[j] = ok ? (unsigned)(((bi * g.IH + yy) * g.IW + x0) * CI + xc4 * 4) * 4u : 0xC0000000u;
+      px0[j] = x0;
       ow += RPX;
 #pragma unroll
       for (int wr = 0; wr < 2; ++wr) {
@@ -563,53 +580,47 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_taprow(const float* __restrict
       }
     }
   };
-  auto load_big = [&](int64_t row0, int kw) {
+  auto load_big = [&](int kw) {
 #pragma unroll
     for (int j = 0; j < LX; ++j) {
-      const int yy = poh[j] * g.SH + kh - g.PT, xx = pow_[j] * g.SW + kw - g.PL;
-      const bool ok = (row0 + xr + j * RPX < m_end) && yy >= 0 && yy < g.IH && xx >= 0 && xx < g.IW;
-      const int64_t src = ok ? ((int64_t)pb[j] * g.IH + yy) * g.IW + xx : 0;
-      px[j] = big4[src * CI4 + xc4];
-      pm[j] = ok ? 1.f : 0.f;
+      const unsigned off = (unsigned)(px0[j] + kw) < (unsigned)g.IW ? pbase[j] + (unsigned)(kw * CI * 4) : 0x80000000u;
+      px[j] = __builtin_amdgcn_raw_buffer_load_b128(brs, off, 0, 0);
     }
   };
-  auto load_small = [&](int64_t row0) {
+  auto load_small = [&](uint32_t row0) {
 #pragma unroll
     for (int j = 0; j < LG; ++j) {
-      const int64_t mm = row0 + j * RPG + gr;
-      pg[j] = small4[(mm < m_end ? mm : m_begin) * CO4 + gc4];
+      const uint32_t mm = row0 + j * RPG + gr;
+      const unsigned off = mm < m_end ? (mm * CO + gc4 * 4) * 4u : 0x80000000u;
+      pg[j] = __builtin_amdgcn_raw_buffer_load_b128(srs, off, 0, 0);
     }
   };
 
-  int64_t row0 = m_begin + wave * R;
+  uint32_t row0 = m_begin + wave * R;
   if (row0 < m_end) {
     decode_tile(row0);
     load_small(row0);
-    load_big(row0, 0);
+    load_big(0);
   }
   for (; row0 < m_end; row0 += 4 * R) {
     WAVE_LDS_SYNC();       // the previous tile's fragment reads are done
 #pragma unroll
-    for (int j = 0; j < LG; ++j) {
-      const int64_t mm = row0 + j * RPG + gr;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(&sG[(j * RPG + gr) * CO + gc4 * 4]) = mm < m_end ? pg[j] : z;
-    }
+    for (int j = 0; j < LG; ++j) *reinterpret_cast<u32x4*>(&sG[(j * RPG + gr) * CO + gc4 * 4]) = pg[j];
     float bv[R / 2][NT];
     const bool more = row0 + 4 * R < m_end;
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
       if (t > 0) WAVE_LDS_SYNC();                 // tap t-1's fragments are in registers
 #pragma unroll
-      for (int j = 0; j < LX; ++j) *reinterpret_cast<f32x4*>(&sX[(j * RPX + xr) * CI + xc4 * 4]) = px[j] * pm[j];
+      for (int j = 0; j < LX; ++j) *reinterpret_cast<u32x4*>(&sX[(j * RPX + xr) * CI + xc4 * 4]) = px[j];
       WAVE_LDS_SYNC();
       // prefetch: the next tap of this tile, or tap 0 (+ the small tile) of the wave's next tile
       if (t + 1 < TG) {
-        load_big(row0, t + 1);
+        load_big(t + 1);
       } else if (more) {
         decode_tile(row0 + 4 * R);
         load_small(row0 + 4 * R);
-        load_big(row0 + 4 * R, 0);
+        load_big(0);
       }
       if (t == 0) {
 #pragma unroll
@@ -683,7 +694,7 @@ static bool run_wgrad_taprow(const float* big, const float* small, float* dW, fl
     return false;
   } else {
   const int64_t M = (int64_t)g.B * g.OH * g.OW;
-  if (g.KW != 5 || M >= (1ll << 31)) return false;
+  if (g.KW != 5 || M * CO * 4 >= (1ll << 31) || (int64_t)g.B * g.IH * g.IW * CI * 4 >= (1ll << 31)) return false;
   int64_t chunks = 512 / g.KH;                     // ~512 blocks: two resident 4-wave blocks per CU
   if (chunks < 1) chunks = 1;
   int64_t rpb = (M + chunks - 1) / chunks;
@@ -741,8 +752,6 @@ bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, flo
 // channels straight from global memory (L2-resident re-reads across taps), the tap's KC x NC weight slice is
 // double-buffered in LDS for the whole block.
 // =================================================================================================
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 // fp32 MFMAs share the SIMD's issue slots with ordinary VALU work: measured (tools/mfma_mix.hip) every VALU instruction
 // next to v_mfma_f32_32x32x2_f32 costs the MFMA 2.5 - 5 cycles, with any number of waves per SIMD.  The first version
 // of this kernel spent ~300 VALU instructions per tap (address arithmetic, padding selects, 64-bit pointers) next to
