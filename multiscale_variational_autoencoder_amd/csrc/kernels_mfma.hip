@@ -766,7 +766,7 @@ bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, flo
 template <int KC, int NC, bool TFORM, int WB>
 __global__ void __launch_bounds__(256, WB == 1 ? 4 : 2)
 k_conv_taps(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
-            float* __restrict__ out, ConvGeom g, unsigned in_bytes, unsigned out_bytes, int dbg) {
+            float* __restrict__ out, ConvGeom g, unsigned in_bytes, unsigned out_bytes) {
   constexpr int KHF = KC / 2, NT = NC / 32, Q = KHF / 4;
   // T-form stages W[tap][n][k] transposed (consecutive threads -> consecutive k): a row pitch of NC + 1 keeps those
   // stores conflict-free (pitch NC put all 32 lanes of a store on one bank: 85 % of the kernel's LDS cycles were bank
@@ -793,8 +793,7 @@ k_conv_taps(const float* __restrict__ in, const float* __restrict__ W, const flo
   if (TFORM) { kh0 = (py + g.PT) % g.SH; kw0 = (px + g.PL) % g.SW; khs = g.SH; kws = g.SW; }
   const int nkh = kh0 < g.KH ? (g.KH - kh0 + khs - 1) / khs : 0;      // <= 8 (launcher)
   const int nkw = kw0 < g.KW ? (g.KW - kw0 + kws - 1) / kws : 0;
-  int ntaps = nkh * nkw;
-  if ((dbg >> 8) && ntaps > (dbg >> 8)) ntaps = dbg >> 8;
+  const int ntaps = nkh * nkw;
   // ---- the pixels this lane FETCHES: slot j = pixel lp + PPI * j of the wave, 16-byte chunk ch.
   // base[j] = byte offset of (window origin pixel, chunk); inv[j] bit t = tap row t leaves the image, bit 8 + t = tap
   // column t does
@@ -882,7 +881,7 @@ k_conv_taps(const float* __restrict__ in, const float* __restrict__ W, const flo
     const int kh = kh0 + th * khs, kw = kw0 + tw * kws;
     const int dy = TFORM ? (py + g.PT - kh) / g.SH : kh - g.PT;
     const int dx = TFORM ? (px + g.PL - kw) / g.SW : kw - g.PL;
-    const unsigned delta = (dbg & 1) ? 0u : (unsigned)((dy * SWw + dx) * KC * 4);
+    const unsigned delta = (unsigned)((dy * SWw + dx) * KC * 4);
     const unsigned sel = (1u << th) | (0x100u << tw);
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
@@ -902,10 +901,10 @@ k_conv_taps(const float* __restrict__ in, const float* __restrict__ W, const flo
   if (ntaps > 0) { fetch_w(0, 0); fetch_a(0, 0); store_w(0); store_a(); }
   int th = 0, tw = 0;                     // the NEXT tap's row / column in the tap list
   for (int it = 0; it < ntaps; ++it) {
-    if (!(dbg & 8)) __syncthreads();       // sW[it % WB] and sA are complete (WB = 2: and sW[(it + 1) & 1] is free)
+    __syncthreads();       // sW[it % WB] and sA are complete (WB = 2: and sW[(it + 1) & 1] is free)
     const bool more = it + 1 < ntaps;
     if (++tw == nkw) { tw = 0; ++th; }
-    if (more) { if (!(dbg & 4)) fetch_w(th, tw); if (!(dbg & 2)) fetch_a(th, tw); }
+    if (more) { fetch_w(th, tw); fetch_a(th, tw); }
     __builtin_amdgcn_sched_barrier(0);
     const float* w = sW[WB == 2 ? (it & 1) : 0];
     // A and B fragments one group of 4 k-steps ahead of the MFMAs that use them
@@ -933,7 +932,7 @@ k_conv_taps(const float* __restrict__ in, const float* __restrict__ W, const flo
     // sA is wave-private and this wave's fragment reads of it are done (their data fed the MFMAs above); a single
     // weight buffer must wait until every wave is through with it
     if (WB == 1 && more) __syncthreads();
-    if (more) { if (!(dbg & 4)) store_w(WB == 2 ? ((it + 1) & 1) : 0); if (!(dbg & 16)) store_a(); }
+    if (more) { store_w(WB == 2 ? ((it + 1) & 1) : 0); store_a(); }
   }
   // epilogue: the bias comes from an UNCONDITIONAL load and the 16 row offsets are read from LDS up front.  With the
   // bias load inside `if (bias)`, every exec-masked store block below carried its own s_waitcnt vmcnt(0) -- i.e. each of
@@ -984,17 +983,16 @@ static void run_conv_taps(const float* in, const float* W, const float* bias, fl
     Mc = (int64_t)g.B * g.OH * g.OW;
   }
   const unsigned in_bytes = (unsigned)((int64_t)g.B * (TFORM ? g.OH * g.OW : g.IH * g.IW) * KC * 4);
-  const int dbg = getenv("MVAE_DBG_SAMEPIX") ? atoi(getenv("MVAE_DBG_SAMEPIX")) : 0;
   const dim3 grid((unsigned)((Mc + 127) / 128), classes);
   const unsigned out_bytes = (unsigned)((int64_t)g.B * (TFORM ? g.IH * g.IW : g.OH * g.OW) * NC * 4);
   // one weight buffer where that is what brings the block down to 40 KB of LDS (4 blocks per CU), two otherwise
   constexpr int WP = TFORM ? NC + 1 : NC;
   constexpr bool kOneBuf = (2 * KC * WP + 4 * 32 * KC) * 4 > 40 * 1024 && (KC * WP + 4 * 32 * KC) * 4 <= 40 * 1024;
-  if (kOneBuf && !(dbg & 32))
+  if (kOneBuf)
     hipLaunchKernelGGL((k_conv_taps<KC, NC, TFORM, kOneBuf ? 1 : 2>), grid, dim3(256), 0, s, in, W, bias, out, g, in_bytes,
-                       out_bytes, dbg);
+                       out_bytes);
   else
-    hipLaunchKernelGGL((k_conv_taps<KC, NC, TFORM, 2>), grid, dim3(256), 0, s, in, W, bias, out, g, in_bytes, out_bytes, dbg);
+    hipLaunchKernelGGL((k_conv_taps<KC, NC, TFORM, 2>), grid, dim3(256), 0, s, in, W, bias, out, g, in_bytes, out_bytes);
 }
 
 bool launch_conv_taps_mfma(bool transposed, const float* in, const float* w, const float* bias, float* out,

@@ -1,5 +1,5 @@
-// Times launch_conv_taps_mfma on the headline 5x5 stride-2 geometry with the kernel's debug switches (MVAE_DBG_SAMEPIX
-// bitmask) -- a perf-debug driver, links the built kernels_mfma.o.
+// Times launch_conv_taps_mfma on the headline 5x5 stride-2 geometry outside the engine -- a perf-debug driver, links the
+// built kernels_mfma.o:   conv_probe <ci> <co> <transposed 0|1> <batch>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -17,21 +17,14 @@ int main(int argc, char** argv) {
   hipMemset(big, 0, (size_t)nb * 32 * 32 * ci * 4); hipMemset(small, 0, (size_t)nb * 16 * 16 * co * 4);
   hipMemset(w, 0, 25 * ci * co * 4); hipMemset(b, 0, 1024);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const int full[] = {0, 1, 2, 4, 6, 8, 14, 22, 30, 0x100, 0x500, 0xa00, 0x1400};
-  const int brief[] = {0, 32, 22};
-  const bool is_brief = argc > 5;
-  const int* masks_p = is_brief ? brief : full;
-  const int nm = is_brief ? 3 : 13;
-  for (int mi = 0; mi < nm; ++mi) {
-    const int m = masks_p[mi];
-    char buf[32]; snprintf(buf, sizeof buf, "%d", m); setenv("MVAE_DBG_SAMEPIX", buf, 1);
+  {
     for (int k = 0; k < 3; ++k) launch_conv_taps_mfma(tr, tr ? small : big, w, b, tr ? big : small, g, 0);
     hipDeviceSynchronize();
     hipEventRecord(e0);
     for (int k = 0; k < 20; ++k) launch_conv_taps_mfma(tr, tr ? small : big, w, b, tr ? big : small, g, 0);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("B %d ci %d co %d T %d dbg 0x%x  %.1f us/launch\n", nb, ci, co, tr, m, ms * 1000 / 20); fflush(stdout);
+    printf("B %d ci %d co %d T %d  %.1f us/launch\n", nb, ci, co, tr, ms * 1000 / 20); fflush(stdout);
   }
   return 0;
 }
