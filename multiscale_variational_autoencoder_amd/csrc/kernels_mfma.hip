@@ -502,6 +502,10 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_rows(const float* __restrict__
 // once per 16-row tile, its fragments kept in registers across the taps) and only the gathered `big` tile changes per
 // tap, prefetched one tap ahead.  Against one-tap-per-block (k_wgrad_rows with grid.y = taps) this cuts the L2 -> CU
 // traffic of the 5x5 convolutions from 25 x (big + small) to 25 x big + 5 x small, which is what bounded them.
+// The KH blocks that walk the same rows read the same `big` pixels: the 1-D grid is laid out so that they are dispatched
+// back to back AND land on the same XCD (workgroup L runs on XCD L % 8), i.e. share an L2: L = xcd + 8 * (kh + KH * group),
+// row chunk = 8 * group + xcd.  With (chunk, kh) as (blockIdx.x, blockIdx.y) the kh passes were a whole tensor sweep
+// apart and `big` came across the fabric ~2.5 times (PMC: 374 MB per launch for a 134 MB tensor).
 template <int CI, int CO, int TG>
 __global__ void __launch_bounds__(256, 2) k_wgrad_taprow(const float* __restrict__ big, const float* __restrict__ small,
                                                          float* __restrict__ dW, float* __restrict__ db, ConvGeom g,
@@ -517,7 +521,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_taprow(const float* __restrict
   float* sX = lds + wave * TILE;
   float* sG = sX + R * CI;
   const int i = lane & 31, h = lane >> 5;
-  const int kh = blockIdx.y;
+  const int xcd = blockIdx.x & 7, kh = (blockIdx.x >> 3) % g.KH;
+  const uint32_t chunk = ((blockIdx.x >> 3) / g.KH) * 8u + xcd;      // may be past the last chunk
+  if ((int64_t)chunk * rows_per_block >= M) return;                  // block-uniform, before any barrier
   const int HWo = g.OH * g.OW;
   const f32x4* big4 = reinterpret_cast<const f32x4*>(big);
   const f32x4* small4 = reinterpret_cast<const f32x4*>(small);
@@ -537,7 +543,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_taprow(const float* __restrict
   for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
 
   // M < 2^31 (launcher): rows are 32-bit
-  const uint32_t m_begin = blockIdx.x * (uint32_t)rows_per_block;
+  uint32_t m_begin = chunk * (uint32_t)rows_per_block;
+  if (m_begin > (uint32_t)M) m_begin = (uint32_t)M;
   uint32_t m_end = m_begin + (uint32_t)rows_per_block;
   if (m_end > (uint32_t)M) m_end = (uint32_t)M;
 
@@ -701,8 +708,8 @@ static bool run_wgrad_taprow(const float* big, const float* small, float* dW, fl
   rpb = (rpb + 63) / 64 * 64;
   if (rpb < 64) rpb = 64;
   chunks = (M + rpb - 1) / rpb;
-  hipLaunchKernelGGL((k_wgrad_taprow<CI, CO, 5>), dim3((unsigned)chunks, g.KH), dim3(256), 0, s, big, small, dW, db, g,
-                     M, rpb);
+  const unsigned groups = (unsigned)((chunks + 7) / 8);
+  hipLaunchKernelGGL((k_wgrad_taprow<CI, CO, 5>), dim3(groups * 8u * g.KH), dim3(256), 0, s, big, small, dW, db, g, M, rpb);
   return true;
   }
 }
@@ -794,6 +801,11 @@ k_conv_taps(const float* __restrict__ in, const float* __restrict__ W, const flo
   const int nkh = kh0 < g.KH ? (g.KH - kh0 + khs - 1) / khs : 0;      // <= 8 (launcher)
   const int nkw = kw0 < g.KW ? (g.KW - kw0 + kws - 1) / kws : 0;
   const int ntaps = nkh * nkw;
+  // F-form with stride 2 reads even input columns for even kw and odd ones for odd kw: the tap list walks a kernel row as
+  // kw = 0, 2, 4, 1, 3, so consecutive taps touch the same cache lines shifted by one output pixel while they are still
+  // in L2 (in natural order the re-use distance is two taps of the whole XCD's traffic, more than the 4 MB L2 holds)
+  const int kw_even = (nkw + 1) / 2;
+  auto col_of = [&](int t) { return (TFORM || g.SW != 2) ? t : (t < kw_even ? 2 * t : 2 * (t - kw_even) + 1); };
   // ---- the pixels this lane FETCHES: slot j = pixel lp + PPI * j of the wave, 16-byte chunk ch.
   // base[j] = byte offset of (window origin pixel, chunk); inv[j] bit t = tap row t leaves the image, bit 8 + t = tap
   // column t does
@@ -826,7 +838,7 @@ k_conv_taps(const float* __restrict__ in, const float* __restrict__ W, const flo
         if ((unsigned)((int)(inv[j] >> 16) + dy) >= (unsigned)SHh) m[j] |= 1u << t;
     }
     for (int t = 0; t < nkw; ++t) {
-      const int kw = kw0 + t * kws;
+      const int kw = kw0 + col_of(t) * kws;
       const int dx = TFORM ? (px + g.PL - kw) / g.SW : kw - g.PL;
 #pragma unroll
       for (int j = 0; j < Q; ++j)
@@ -848,7 +860,7 @@ k_conv_taps(const float* __restrict__ in, const float* __restrict__ W, const flo
   constexpr int WPT = KC * NC / 256;                     // weights per thread per tap
   float wtmp[WPT];
   auto fetch_w = [&](int th, int tw) {
-    const int kh = kh0 + th * khs, kw = kw0 + tw * kws;
+    const int kh = kh0 + th * khs, kw = kw0 + col_of(tw) * kws;
     const float* wt = W + (int64_t)(kh * g.KW + kw) * KC * NC;
     if (TFORM) {
 #pragma unroll
@@ -878,7 +890,7 @@ k_conv_taps(const float* __restrict__ in, const float* __restrict__ W, const flo
   };
   u32x4 atmp[Q];
   auto fetch_a = [&](int th, int tw) {
-    const int kh = kh0 + th * khs, kw = kw0 + tw * kws;
+    const int kh = kh0 + th * khs, kw = kw0 + col_of(tw) * kws;
     const int dy = TFORM ? (py + g.PT - kh) / g.SH : kh - g.PT;
     const int dx = TFORM ? (px + g.PL - kw) / g.SW : kw - g.PL;
     const unsigned delta = (unsigned)((dy * SWw + dx) * KC * 4);
