@@ -65,6 +65,70 @@ __global__ void __launch_bounds__(256) k_skinny_mfma(const float* __restrict__ A
   }
 }
 
+// The same product for K % 256 == 0, built for latency instead of a k loop: a block = 32 batch rows x 256 reduction
+// indices, wave w takes 64 of them (lane half h: 32), issues ALL its loads as one batch (8 x 16 B of its A row, the 32
+// matching B values), then runs its 32 MFMAs; the 4 waves' tiles are summed through LDS and leave as ONE atomic set per
+// block.  The looped kernel above waited out a full memory round trip per 4 MFMAs (B = 512, K = 8192: 32 trips, 38 us).
+template <bool NT>
+__global__ void __launch_bounds__(256) k_skinny_mfma256(const float* __restrict__ A, const float* __restrict__ W1,
+                                                        const float* __restrict__ W2, const float* __restrict__ bias1,
+                                                        const float* __restrict__ bias2, float* __restrict__ out1,
+                                                        float* __restrict__ out2, int B, int K, int N1, int N2,
+                                                        int ngroups) {
+  __shared__ float red[3][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rt = blockIdx.x / ngroups, kg = blockIdx.x % ngroups;
+  const int i = lane & 31, h = lane >> 5;
+  const int row = rt * 32 + i;
+  const int rowc = row < B ? row : B - 1;                  // clamped: the extra rows are never written
+  const int k0 = kg * 256 + wave * 64 + h * 32;
+  // this lane's B-operand column; lanes past N1 + N2 read column 0 of W1 and are never written either
+  const bool two = i >= N1 && i < N1 + N2;
+  const float* Wc = two ? W2 : W1;
+  const int Nx = two ? N2 : N1;
+  const int jx = two ? i - N1 : (i < N1 ? i : 0);
+  f32x4 a4[8];
+  float bq[32];
+  const f32x4* ap = reinterpret_cast<const f32x4*>(A + (int64_t)rowc * K + k0);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) a4[q] = ap[q];
+  if (NT) {
+    const f32x4* bp = reinterpret_cast<const f32x4*>(Wc + (int64_t)jx * K + k0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 v = bp[q];
+      bq[q * 4] = v[0]; bq[q * 4 + 1] = v[1]; bq[q * 4 + 2] = v[2]; bq[q * 4 + 3] = v[3];
+    }
+  } else {
+    const float* bp = Wc + (int64_t)k0 * Nx + jx;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) bq[e] = bp[(int64_t)e * Nx];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q][e], bq[q * 4 + e], acc, 0, 0, 0);
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave != 0 || i >= N1 + N2) return;
+  float* out = two ? out2 : out1;
+  const float* bias = two ? bias2 : bias1;
+  const float bv = (kg == 0 && bias) ? bias[jx] : 0.f;     // every output element: one (lane, register); chunk 0 adds the bias
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int orow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const float v = acc[r] + red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + bv;
+    if (orow < B) atomicAdd(&out[(int64_t)orow * Nx + jx], v);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_dense_bwd2(const float* __restrict__ g1, const float* __restrict__ g2,
                                                     const float* __restrict__ W1, const float* __restrict__ W2,
                                                     float* __restrict__ out, int B, int K, int Z) {
@@ -284,6 +348,13 @@ static void run_skinny(bool nt, const float* A, const float* W1, const float* W2
                        float* o1, float* o2, int B, int K, int N1, int N2, hipStream_t s) {
   launch_zero(o1, (int64_t)B * N1, s);
   if (N2) launch_zero(o2, (int64_t)B * N2, s);
+  if (K % 256 == 0 && N1 >= 1) {
+    const int ngroups = K / 256;
+    dim3 grid((unsigned)(((B + 31) / 32) * ngroups));
+    if (nt) hipLaunchKernelGGL(k_skinny_mfma256<true>, grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, ngroups);
+    else hipLaunchKernelGGL(k_skinny_mfma256<false>, grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, ngroups);
+    return;
+  }
   int KC = 256;
   while (KC > 8 && (int64_t)((B + 31) / 32) * ((K + KC - 1) / KC) < 512 && KC > 32) KC /= 2;   // >= ~512 waves
   const int nchunks = (K + KC - 1) / KC;
