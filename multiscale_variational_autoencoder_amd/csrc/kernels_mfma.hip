@@ -29,6 +29,18 @@ static int big_grid_cus() {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// image index of a row: rows_per_image is a power of two for every feature map of the reference's configs -> a shift.
+// (As `row / rows_per_image` on int64 the tile loops carried a ~100-instruction software division per use -- VALU work
+// that fp32 MFMAs do not overlap with, see k_conv_taps.)   Rows < 2^31 (launchers).
+struct ImgOf {
+  uint32_t rpi;
+  int sh;
+  __device__ explicit ImgOf(int64_t rows_per_image)
+      : rpi((uint32_t)rows_per_image),
+        sh((rows_per_image & (rows_per_image - 1)) == 0 ? 63 - __builtin_clzll((unsigned long long)rows_per_image) : -1) {}
+  __device__ uint32_t operator()(int64_t row) const { return sh >= 0 ? (uint32_t)row >> sh : (uint32_t)row / rpi; }
+};
+
 // A wave's LDS instructions execute in issue order, so data one lane wrote is visible to a later ds_read of any
 // lane of the SAME wave; only the compiler has to be kept from reordering across the hand-off.
 #define WAVE_LDS_SYNC()                                      \
@@ -107,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
   // the kernel is limited by bytes in flight, not by MFMA or LDS work.
   Stage A, Bq;
   A.g0 = A.g1 = Bq.g0 = Bq.g1 = f32x4{1.f, 1.f, 1.f, 1.f};
-  const uint32_t rpi32 = (uint32_t)rows_per_image;
+  const ImgOf img_of(rows_per_image);
   const f32x4* G4 = reinterpret_cast<const f32x4*>(pre.gate ? pre.gate : X);   // dummy source keeps the load unconditional
   const f32x4* RS4 = residual ? R4 : reinterpret_cast<const f32x4*>(Y);        // likewise ([M,N] like the residual)
   auto load_tile = [&](int64_t tile, Stage& S) {
@@ -115,7 +127,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
     if constexpr (FAST) {
 #pragma unroll
       for (int j = 0; j < LD; ++j) S.st[j] = X4[(row0 + j * RPL + lr) * C4 + lc4];
-      const uint32_t b0 = pre.gate ? (uint32_t)row0 / rpi32 : 0u, b1 = pre.gate ? (uint32_t)(row0 + 16) / rpi32 : 0u;
+      const uint32_t b0 = pre.gate ? img_of(row0) : 0u, b1 = pre.gate ? img_of(row0 + 16) : 0u;
       S.g0 = G4[(int64_t)b0 * C4 + lc4];
       S.g1 = G4[(int64_t)b1 * C4 + lc4];
     } else {
@@ -126,9 +138,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
         S.st[j] = row < M ? X4[row * C4 + lc4] : z;
       }
       if (pre.gate && row0 < M) {
-        S.g0 = reinterpret_cast<const f32x4*>(pre.gate)[(int64_t)((uint32_t)row0 / rpi32) * C4 + lc4];
+        S.g0 = reinterpret_cast<const f32x4*>(pre.gate)[(int64_t)img_of(row0) * C4 + lc4];
         const uint32_t r1 = (uint32_t)(row0 + 16 < M ? row0 + 16 : row0);
-        S.g1 = reinterpret_cast<const f32x4*>(pre.gate)[(int64_t)(r1 / rpi32) * C4 + lc4];
+        S.g1 = reinterpret_cast<const f32x4*>(pre.gate)[(int64_t)img_of(r1) * C4 + lc4];
       }
     }
   };
@@ -253,7 +265,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_rows(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) dsum[e] += __shfl_xor(dsum[e], off, 64);
       if (lane < N4 && row0 < M) {
-        float* dst = dot_out + (row0 / rows_per_image) * N + sc4 * 4;
+        float* dst = dot_out + (int64_t)img_of(row0) * N + sc4 * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(dst + e, dsum[e]);
       }
@@ -1061,6 +1073,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
   // dot_out has `dslots` copies `dstride` floats apart (block b adds into copy b % dslots): with large feature maps
   // thousands of tiles add into the 256 bytes of one image's gate gradient (C256-nb: 8192 adds per line, a ~200 us tail)
   if (dot_out) dot_out += (int64_t)(blockIdx.x % dslots) * dstride;
+  const ImgOf img_of(rows_per_image);
   constexpr bool FAST = MODE != 0;
   constexpr int KH = C / 2, NT = C / 32, C4 = C / 4, MASK = C4 - 1;
   constexpr int WN = NT, WR = 4 / WN, TR = 32 * WR;        // block tile = TR rows
@@ -1147,9 +1160,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
     float gl[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
-      if constexpr (MODE == 1) gl[kt] = gate[(rowh / rows_per_image) * C + kt * 32 + i];
+      if constexpr (MODE == 1) gl[kt] = gate[(int64_t)img_of(rowh) * C + kt * 32 + i];
       else if constexpr (MODE == 2) gl[kt] = 1.0f;
-      else gl[kt] = (gate && row0 < M) ? gate[(rowh / rows_per_image) * C + kt * 32 + i] : 1.0f;
+      else gl[kt] = (gate && row0 < M) ? gate[(int64_t)img_of(rowh) * C + kt * 32 + i] : 1.0f;
     }
     __syncthreads();                                       // previous tile fully consumed by all waves
 #pragma unroll
@@ -1231,8 +1244,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual(const float* __restrict__ 
     if (has_dot) {
       dsum[0] += __shfl_xor(dsum[0], 32, 64);
       dsum[1] += __shfl_xor(dsum[1], 32, 64);
-      if (h == 0 && (FAST || row0 < M)) atomicAdd(dot_out + (row0 / rows_per_image) * C + n0 + i, dsum[0]);
-      if (h == 1 && (FAST || row0 + 16 < M)) atomicAdd(dot_out + ((row0 + 16) / rows_per_image) * C + n0 + i, dsum[1]);
+      if (h == 0 && (FAST || row0 < M)) atomicAdd(dot_out + (int64_t)img_of(row0) * C + n0 + i, dsum[0]);
+      if (h == 1 && (FAST || row0 + 16 < M)) atomicAdd(dot_out + (int64_t)img_of(row0 + 16) * C + n0 + i, dsum[1]);
     }
     if constexpr (MODE == 0) {
       if (residual && tile + g1 < ntiles) load_res(tile + g1);
@@ -1330,6 +1343,7 @@ __global__ void __launch_bounds__(256, GR ? 2 : 4) k_conv0_tile(const float* __r
   constexpr int WN = NT, WR = 4 / WN, TR = 32 * WR;
   constexpr int LD = TR * C4 / 256;
   static_assert(256 / C4 == 16 || !GR, "gated form: one staged float4 per 16-row group");
+  const ImgOf img_of(rows_per_image);
   __shared__ __attribute__((aligned(16))) float sX[TR * C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = wave % WN, rw = wave / WN, n0 = nw * 32;
@@ -1351,7 +1365,7 @@ __global__ void __launch_bounds__(256, GR ? 2 : 4) k_conv0_tile(const float* __r
     if constexpr (GR) {
 #pragma unroll
       for (int j = 0; j < LD; ++j)
-        S.g[j] = G4[((tile * TR + j * (256 / C4)) / rows_per_image) * C4 + threadIdx.x % C4];
+        S.g[j] = G4[(int64_t)img_of(tile * TR + j * (256 / C4)) * C4 + threadIdx.x % C4];
     }
   };
   float res[GR ? 16 : 1];
