@@ -123,6 +123,83 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const f32x4* __restrict__ i
   }
 }
 
+// ---- small feature maps (W <= 16): whole images in LDS --------------------------------------------------------------
+// The ring kernels keep (FIFO depth) x (items per thread per row) 16-byte loads in flight per thread; a 16-wide row is
+// ONE item per thread, so a CU had 32 KB in flight and the 16x16 maps of B = 512 ran at 3.3 TB/s (Little's law: 5 TB/s
+// x ~2.5 us needs ~50 KB per CU).  Here a block takes IPB = 256 / (H * C4) whole images (256 * W float4 = W loads per
+// thread, all issued at once), and thread (image, y, c4) then walks its output row with a 3x3 register window fed from
+// LDS.  One memory round trip per image instead of a pipeline of H of them; the GAP needs no atomics.
+template <int W_>
+__global__ void __launch_bounds__(256, 2) k_dw_fwd_img(const f32x4* __restrict__ in, const f32x4* __restrict__ w,
+                                                       const f32x4* __restrict__ bias, f32x4* __restrict__ out,
+                                                       float* __restrict__ gap, int H, int C4, float inv_hw) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  f32x4* tile = reinterpret_cast<f32x4*>(dyn_lds);             // [IPB][H][W_][C4]
+  constexpr int total = 256 * W_;
+  const int64_t base = (int64_t)blockIdx.x * total;
+  f32x4 ld[W_];
+#pragma unroll
+  for (int j = 0; j < W_; ++j) ld[j] = in[base + threadIdx.x + 256 * j];
+  const int c4 = threadIdx.x % C4, y = (threadIdx.x / C4) % H, img = threadIdx.x / (C4 * H);
+  f32x4 wt[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wt[k] = w[k * C4 + c4];
+  const f32x4 bs = bias[c4];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < W_; ++j) tile[threadIdx.x + 256 * j] = ld[j];
+  __syncthreads();
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int ipi = H * W_ * C4;
+  const f32x4* rowp[3];
+  bool rok[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int yy = y + a - 1;
+    rok[a] = yy >= 0 && yy < H;
+    rowp[a] = tile + img * ipi + (rok[a] ? yy : y) * W_ * C4 + c4;
+  }
+  // window columns x-1, x, x+1 of the three rows; column -1 / W_ are zero
+  f32x4 win[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { win[a][1] = zero; win[a][2] = rok[a] ? rowp[a][0] : zero; }
+  f32x4 gsum = zero;
+  f32x4* orow = out + base + img * ipi + y * W_ * C4 + c4;
+#pragma unroll
+  for (int x = 0; x < W_; ++x) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      win[a][0] = win[a][1]; win[a][1] = win[a][2];
+      win[a][2] = (x + 1 < W_ && rok[a]) ? rowp[a][(x + 1) * C4] : zero;
+    }
+    f32x4 acc = bs;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) acc += wt[a * 3 + e] * win[a][e];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = acc[q] > 0.f ? acc[q] : 0.f;
+    orow[x * C4] = acc;
+    gsum += acc;
+  }
+  // GAP: the H rows of (image, c4) through LDS (the tile is free once every thread has its outputs)
+  __syncthreads();
+  tile[threadIdx.x] = gsum;
+  __syncthreads();
+  if (y == 0) {
+    f32x4 t = zero;
+    for (int r = 0; r < H; ++r) t += tile[(img * H + r) * C4 + c4];
+    *reinterpret_cast<f32x4*>(gap + ((int64_t)blockIdx.x * (256 / (C4 * H)) + img) * C4 * 4 + c4 * 4) = t * inv_hw;
+  }
+}
+
+static bool dw_img_shape(int B, int H, int W, int C) {
+  if (C % 4 || (W != 4 && W != 8 && W != 16)) return false;
+  const int rows = H * (C / 4);                                // (y, c4) pairs per image
+  if (rows < 1 || rows > 256 || 256 % rows) return false;
+  return B % (256 / rows) == 0;
+}
+
 // LSB = the ReLU mask (t1 > 0) arrives in the mantissa LSB of dt2 (written by k_gemm_dual's conv2 pair): t1 is not read
 template <bool LSB>
 __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ dt2, const f32x4* __restrict__ t1,
@@ -282,6 +359,17 @@ static bool dw_geom(int H, int W, int C, DwGeom* g, size_t* lds) {
 // t1 = relu(dw(t0) + b) and gap = mean_hw(t1) in one pass.  false = shape not covered.
 bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* out, float* gap, int B, int H, int W,
                        int C, hipStream_t s) {
+  if (dw_img_shape(B, H, W, C)) {
+    const int ipb = 256 / (H * (C / 4));
+    const dim3 grid((unsigned)(B / ipb));
+    const size_t bytes = (size_t)256 * W * sizeof(f32x4);
+    const float inv = 1.0f / (float)(H * W);
+#define MVAE_DWI(W_) hipLaunchKernelGGL(k_dw_fwd_img<W_>, grid, dim3(256), bytes, s, (const f32x4*)in, (const f32x4*)w, \
+                                        (const f32x4*)b, (f32x4*)out, gap, H, C / 4, inv)
+    if (W == 16) MVAE_DWI(16); else if (W == 8) MVAE_DWI(8); else MVAE_DWI(4);
+#undef MVAE_DWI
+    return true;
+  }
   DwGeom g;
   size_t lds;
   if (!dw_geom(H, W, C, &g, &lds) || B > 65535 || (H % 4) != 0) return false;
