@@ -129,10 +129,10 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const f32x4* __restrict__ i
 // x ~2.5 us needs ~50 KB per CU).  Here a block takes IPB = 256 / (H * C4) whole images (256 * W float4 = W loads per
 // thread, all issued at once), and thread (image, y, c4) then walks its output row with a 3x3 register window fed from
 // LDS.  One memory round trip per image instead of a pipeline of H of them; the GAP needs no atomics.
-template <int W_>
+template <int W_, int C4>
 __global__ void __launch_bounds__(256, 2) k_dw_fwd_img(const f32x4* __restrict__ in, const f32x4* __restrict__ w,
                                                        const f32x4* __restrict__ bias, f32x4* __restrict__ out,
-                                                       float* __restrict__ gap, int H, int C4, float inv_hw) {
+                                                       float* __restrict__ gap, int H, float inv_hw) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   f32x4* tile = reinterpret_cast<f32x4*>(dyn_lds);             // [IPB][H][W_][C4]
   constexpr int total = 256 * W_;
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256, 2) k_dw_fwd_img(const f32x4* __restrict__
 }
 
 static bool dw_img_shape(int B, int H, int W, int C) {
-  if (C % 4 || (W != 4 && W != 8 && W != 16)) return false;
+  if ((C != 32 && C != 64) || (W != 4 && W != 8 && W != 16)) return false;   // channel count is a template parameter
   const int rows = H * (C / 4);                                // (y, c4) pairs per image
   if (rows < 1 || rows > 256 || 256 % rows) return false;
   return B % (256 / rows) == 0;
@@ -343,6 +343,117 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
 
 #undef RING
 
+// Backward for the same small maps (ReLU mask in the LSB of dt2, see k_dw_bwd_ring<true>): the block's images of raw
+// dt2 go to LDS, thread (image, y, c4) fetches its own t0 row straight into registers (no neighbourhood needed) and walks
+// the row with a 3x3 window of d1 = (dt2 * gate + dgap / hw) * mask, formed as the window is filled.
+template <int W_, int C4>
+__global__ void __launch_bounds__(256, 2) k_dw_bwd_img(const f32x4* __restrict__ dt2, const f32x4* __restrict__ t0,
+                                                       const f32x4* __restrict__ w, const f32x4* __restrict__ gate,
+                                                       const f32x4* __restrict__ dgap, f32x4* __restrict__ dt0,
+                                                       float* __restrict__ dW, float* __restrict__ db, int H,
+                                                       float inv_hw, int nslots, int64_t slot_stride) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  f32x4* tile = reinterpret_cast<f32x4*>(dyn_lds);             // [IPB][H][W_][C4] raw dt2
+  constexpr int total = 256 * W_;
+  const int64_t base = (int64_t)blockIdx.x * total;
+  const int c4 = threadIdx.x % C4, y = (threadIdx.x / C4) % H, img = threadIdx.x / (C4 * H);
+  const int ipi = H * W_ * C4, ipb = 256 / (C4 * H);
+  // the t0 row rides a 4-deep register FIFO (fetched four steps ahead of its use): the whole row next to the 19 float4
+  // accumulators and the window does not fit 256 registers
+  constexpr int FD = W_ < 4 ? W_ : 4;
+  f32x4 ld[W_], t0q[FD];
+#pragma unroll
+  for (int j = 0; j < W_; ++j) ld[j] = dt2[base + threadIdx.x + 256 * j];
+  const f32x4* t0p = t0 + base + img * ipi + y * W_ * C4 + c4;
+#pragma unroll
+  for (int x = 0; x < FD; ++x) t0q[x] = t0p[x * C4];
+  const int64_t bimg = (int64_t)blockIdx.x * ipb + img;
+  const f32x4 gg = gate[bimg * C4 + c4];
+  const f32x4 dg = dgap[bimg * C4 + c4] * inv_hw;
+  f32x4 wt[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wt[k] = w[k * C4 + c4];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < W_; ++j) tile[threadIdx.x + 256 * j] = ld[j];
+  __syncthreads();
+  f32x4 aw[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) aw[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 ab = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // win[a][e] = d1(y - a + 1, x - e + 1): the position read by output pixel (y,x)'s transposed tap (a,e)
+  const f32x4* rowp[3];
+  bool rok[3];
+  unsigned rokm[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int yy = y - a + 1;
+    rok[a] = yy >= 0 && yy < H;
+    rokm[a] = rok[a] ? 1u : 0u;
+    rowp[a] = tile + img * ipi + (rok[a] ? yy : y) * W_ * C4 + c4;
+  }
+  auto d1_at = [&](int a, int xx) {                            // xx in [0, W_)
+    const f32x4 r = rowp[a][xx * C4];
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                              // branch-free: one select on (row valid) & (mask bit)
+      const float t = r[q] * gg[q] + dg[q];
+      v[q] = (__float_as_uint(r[q]) & rokm[a]) != 0u ? t : 0.f;
+    }
+    return v;
+  };
+  f32x4 win[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { win[a][1] = zero; win[a][0] = d1_at(a, 0); }
+  f32x4* orow = dt0 + base + img * ipi + y * W_ * C4 + c4;
+#pragma unroll
+  for (int x = 0; x < W_; ++x) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      win[a][2] = win[a][1]; win[a][1] = win[a][0];
+      win[a][0] = x + 1 < W_ ? d1_at(a, x + 1) : zero;
+    }
+    const f32x4 tv = t0q[x % FD];
+    if (x + FD < W_) t0q[x % FD] = t0p[(x + FD) * C4];
+    f32x4 acc = zero;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        acc += wt[a * 3 + e] * win[a][e];
+        aw[a * 3 + e] += tv * win[a][e];
+      }
+    ab += win[1][1];
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = tv[q] > 0.f ? acc[q] : 0.f;
+    orow[x * C4] = r;
+    __builtin_amdgcn_sched_barrier(0);                 // keeps the scheduler from hoisting every later window read up here
+  }
+  // ---- block reduction of the 10 float4 accumulators over the threads that share c4, one atomic set per block
+  __syncthreads();
+  f32x4* red = tile;                                   // 4 * 10 * C4 float4 <= 256 * W_
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    f32x4 v = k < 9 ? aw[k < 9 ? k : 0] : ab;
+    for (int off = C4; off < 64; off <<= 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += __shfl_xor(v[q], off, 64);
+    }
+    if (lane < C4) red[(wave * 10 + k) * C4 + lane] = v;
+  }
+  __syncthreads();
+  const int64_t slot = (int64_t)(blockIdx.x % nslots) * slot_stride;
+  for (int idx = threadIdx.x; idx < 10 * C4 * 4; idx += 256) {
+    const int q = idx & 3, cc = (idx >> 2) % C4, k = (idx >> 2) / C4;
+    float t = 0.f;
+    for (int wv = 0; wv < 4; ++wv) t += red[(wv * 10 + k) * C4 + cc][q];
+    atomicAdd((k < 9 ? dW + slot + (int64_t)k * C4 * 4 : db + slot) + cc * 4 + q, t);
+  }
+}
+
 static bool dw_geom(int H, int W, int C, DwGeom* g, size_t* lds) {
   if (C % 4) return false;
   const int C4 = C / 4;
@@ -364,8 +475,13 @@ bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* o
     const dim3 grid((unsigned)(B / ipb));
     const size_t bytes = (size_t)256 * W * sizeof(f32x4);
     const float inv = 1.0f / (float)(H * W);
-#define MVAE_DWI(W_) hipLaunchKernelGGL(k_dw_fwd_img<W_>, grid, dim3(256), bytes, s, (const f32x4*)in, (const f32x4*)w, \
-                                        (const f32x4*)b, (f32x4*)out, gap, H, C / 4, inv)
+#define MVAE_DWI(W_)                                                                                                  \
+  do {                                                                                                                \
+    if (C == 64) hipLaunchKernelGGL((k_dw_fwd_img<W_, 16>), grid, dim3(256), bytes, s, (const f32x4*)in,             \
+                                    (const f32x4*)w, (const f32x4*)b, (f32x4*)out, gap, H, inv);                     \
+    else hipLaunchKernelGGL((k_dw_fwd_img<W_, 8>), grid, dim3(256), bytes, s, (const f32x4*)in, (const f32x4*)w,     \
+                            (const f32x4*)b, (f32x4*)out, gap, H, inv);                                              \
+  } while (0)
     if (W == 16) MVAE_DWI(16); else if (W == 8) MVAE_DWI(8); else MVAE_DWI(4);
 #undef MVAE_DWI
     return true;
@@ -384,6 +500,25 @@ bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* o
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
                          const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
                          int W, int C, hipStream_t s) {
+  // (16 wide x 64 channels stays on the ring kernel: same 33 us, and this one needs ~56 spilled registers there)
+  if (mask_in_lsb && dw_img_shape(B, H, W, C) && !(W == 16 && C == 64) && 40 * (C / 4) <= 256 * W) {
+    const int ipb = 256 / (H * (C / 4));
+    const dim3 grid((unsigned)(B / ipb));
+    const size_t bytes = (size_t)256 * W * sizeof(f32x4);
+    const float inv = 1.0f / (float)(H * W);
+#define MVAE_DWB(W_)                                                                                                  \
+  do {                                                                                                                \
+    if (C == 64) hipLaunchKernelGGL((k_dw_bwd_img<W_, 16>), grid, dim3(256), bytes, s, (const f32x4*)dt2,            \
+                                    (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap,       \
+                                    (f32x4*)dt0, sl.at(dW), sl.at(db), H, inv, sl.count(), sl.stride);               \
+    else hipLaunchKernelGGL((k_dw_bwd_img<W_, 8>), grid, dim3(256), bytes, s, (const f32x4*)dt2, (const f32x4*)t0,   \
+                            (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0, sl.at(dW),         \
+                            sl.at(db), H, inv, sl.count(), sl.stride);                                               \
+  } while (0)
+    if (W == 16) MVAE_DWB(16); else if (W == 8) MVAE_DWB(8); else MVAE_DWB(4);
+#undef MVAE_DWB
+    return true;
+  }
   DwGeom g;
   size_t lds;
   if (!dw_geom(H, W, C, &g, &lds) || g.C4 > 64) return false;
