@@ -205,6 +205,8 @@ bool launch_head_bwd(const float* x, const float* dy, const float* W, const floa
                      const float* shift, const float* mean, const float* invstd, float* S, float* dW, float* db,
                      float* dgamma, float* dbeta, float* dout, int64_t M, int dc, int C, GradSlots sl, hipStream_t s);
 // sliding-row depthwise kernels (kernels_dw.hip); false = shape not covered
+// true where the whole-image kernels (k_dw_fwd_img / k_dw_bwd_img, feature maps <= 16 wide) take the launch
+bool dw_uses_img(bool backward, bool mask_in_lsb, int B, int H, int W, int C);
 bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* out, float* gap, int B, int H, int W,
                        int C, hipStream_t s);
 constexpr int kDwMaxBlocks = 1024;     // partial-sum scratch: kDwMaxBlocks * 10 * C floats

@@ -467,10 +467,17 @@ static bool dw_geom(int H, int W, int C, DwGeom* g, size_t* lds) {
   return *lds <= 64 * 1024;
 }
 
+bool dw_uses_img(bool backward, bool mask_in_lsb, int B, int H, int W, int C) {
+  if (!dw_img_shape(B, H, W, C)) return false;
+  if (!backward) return true;
+  // (16 wide x 64 channels stays on the ring kernel: same 33 us, and the image kernel needs ~56 spilled registers there)
+  return mask_in_lsb && !(W == 16 && C == 64) && 40 * (C / 4) <= 256 * W;
+}
+
 // t1 = relu(dw(t0) + b) and gap = mean_hw(t1) in one pass.  false = shape not covered.
 bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* out, float* gap, int B, int H, int W,
                        int C, hipStream_t s) {
-  if (dw_img_shape(B, H, W, C)) {
+  if (dw_uses_img(false, false, B, H, W, C)) {
     const int ipb = 256 / (H * (C / 4));
     const dim3 grid((unsigned)(B / ipb));
     const size_t bytes = (size_t)256 * W * sizeof(f32x4);
@@ -500,8 +507,7 @@ bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* o
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
                          const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
                          int W, int C, hipStream_t s) {
-  // (16 wide x 64 channels stays on the ring kernel: same 33 us, and this one needs ~56 spilled registers there)
-  if (mask_in_lsb && dw_img_shape(B, H, W, C) && !(W == 16 && C == 64) && 40 * (C / 4) <= 256 * W) {
+  if (dw_uses_img(true, mask_in_lsb, B, H, W, C)) {
     const int ipb = 256 / (H * (C / 4));
     const dim3 grid((unsigned)(B / ipb));
     const size_t bytes = (size_t)256 * W * sizeof(f32x4);

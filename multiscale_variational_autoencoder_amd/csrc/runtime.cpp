@@ -495,7 +495,8 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
   if (!tiled0) launch_conv_f(x, P + m.w0, P + m.b0, nullptr, m.t0, g, none, ACT_RELU, s);
   bool fused_dw;
   {
-    ProfScope ps("k_dw_fwd_ring<true>", 8.0 * B * m.H * m.W * c, 20.0 * B * m.H * m.W * c, s);
+    ProfScope ps(dw_uses_img(false, false, B, m.H, m.W, c) ? "k_dw_fwd_img" : "k_dw_fwd_ring<true>", 8.0 * B * m.H * m.W * c,
+                 20.0 * B * m.H * m.W * c, s);
     fused_dw = launch_dw_fwd_gap(m.t0, P + m.wd, P + m.bd, m.t1, m.gap, B, m.H, m.W, c, s);
   }
   if (!fused_dw) {
@@ -568,7 +569,8 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   float* bufC = acquire(h, sc, s);
   bool fused_dw;
   {
-    ProfScope ps(dual2 ? "k_dw_bwd_ring<true>" : "k_dw_bwd_ring<false>", (dual2 ? 12.0 : 16.0) * B * HW * c,
+    ProfScope ps(dw_uses_img(true, dual2, B, m.H, m.W, c) ? "k_dw_bwd_img" : (dual2 ? "k_dw_bwd_ring<true>" : "k_dw_bwd_ring<false>"),
+                 (dual2 ? 12.0 : 16.0) * B * HW * c,
                  40.0 * B * HW * c, s);            // 3 passes when t1 is not read (mask in the LSB of dt2)
     fused_dw = launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC, G + m.wd, G + m.bd, h->gslots, dual2, B,
                                    m.H, m.W, c, s);
