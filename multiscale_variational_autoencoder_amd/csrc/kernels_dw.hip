@@ -346,25 +346,28 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
 // Backward for the same small maps (ReLU mask in the LSB of dt2, see k_dw_bwd_ring<true>): the block's images of raw
 // dt2 go to LDS, thread (image, y, c4) fetches its own t0 row straight into registers (no neighbourhood needed) and walks
 // the row with a 3x3 window of d1 = (dt2 * gate + dgap / hw) * mask, formed as the window is filled.
-template <int W_, int C4>
-__global__ void __launch_bounds__(256, 2) k_dw_bwd_img(const f32x4* __restrict__ dt2, const f32x4* __restrict__ t0,
+// XS = 2: two threads share an output row (half of it each), 512 threads per block -- the 16-wide x 64-channel case, where
+// one thread per row needs more than 256 registers
+template <int W_, int C4, int XS>
+__global__ void __launch_bounds__(256 * XS, XS == 2 ? 1 : 2) k_dw_bwd_img(const f32x4* __restrict__ dt2, const f32x4* __restrict__ t0,
                                                        const f32x4* __restrict__ w, const f32x4* __restrict__ gate,
                                                        const f32x4* __restrict__ dgap, f32x4* __restrict__ dt0,
                                                        float* __restrict__ dW, float* __restrict__ db, int H,
                                                        float inv_hw, int nslots, int64_t slot_stride) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   f32x4* tile = reinterpret_cast<f32x4*>(dyn_lds);             // [IPB][H][W_][C4] raw dt2
-  constexpr int total = 256 * W_;
+  constexpr int total = 256 * W_, NTHR = 256 * XS, XL = W_ / XS;       // XL = columns per thread
   const int64_t base = (int64_t)blockIdx.x * total;
-  const int c4 = threadIdx.x % C4, y = (threadIdx.x / C4) % H, img = threadIdx.x / (C4 * H);
+  const int rowid = threadIdx.x % 256, x0 = (threadIdx.x / 256) * XL;
+  const int c4 = rowid % C4, y = (rowid / C4) % H, img = rowid / (C4 * H);
   const int ipi = H * W_ * C4, ipb = 256 / (C4 * H);
   // the t0 row rides a 4-deep register FIFO (fetched four steps ahead of its use): the whole row next to the 19 float4
   // accumulators and the window does not fit 256 registers
-  constexpr int FD = W_ < 4 ? W_ : 4;
-  f32x4 ld[W_], t0q[FD];
+  constexpr int FD = XL < 4 ? XL : 4;
+  f32x4 ld[XL], t0q[FD];
 #pragma unroll
-  for (int j = 0; j < W_; ++j) ld[j] = dt2[base + threadIdx.x + 256 * j];
-  const f32x4* t0p = t0 + base + img * ipi + y * W_ * C4 + c4;
+  for (int j = 0; j < XL; ++j) ld[j] = dt2[base + threadIdx.x + NTHR * j];
+  const f32x4* t0p = t0 + base + img * ipi + (y * W_ + x0) * C4 + c4;
 #pragma unroll
   for (int x = 0; x < FD; ++x) t0q[x] = t0p[x * C4];
   const int64_t bimg = (int64_t)blockIdx.x * ipb + img;
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(256, 2) k_dw_bwd_img(const f32x4* __restrict__
   for (int k = 0; k < 9; ++k) wt[k] = w[k * C4 + c4];
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int j = 0; j < W_; ++j) tile[threadIdx.x + 256 * j] = ld[j];
+  for (int j = 0; j < XL; ++j) tile[threadIdx.x + NTHR * j] = ld[j];
   __syncthreads();
   f32x4 aw[9];
 #pragma unroll
@@ -391,9 +394,9 @@ __global__ void __launch_bounds__(256, 2) k_dw_bwd_img(const f32x4* __restrict__
     const int yy = y - a + 1;
     rok[a] = yy >= 0 && yy < H;
     rokm[a] = rok[a] ? 1u : 0u;
-    rowp[a] = tile + img * ipi + (rok[a] ? yy : y) * W_ * C4 + c4;
+    rowp[a] = tile + img * ipi + ((rok[a] ? yy : y) * W_ + x0) * C4 + c4;      // column x0 of the row
   }
-  auto d1_at = [&](int a, int xx) {                            // xx in [0, W_)
+  auto d1_at = [&](int a, int xx) {                            // column x0 + xx, inside the row
     const f32x4 r = rowp[a][xx * C4];
     f32x4 v;
 #pragma unroll
@@ -403,19 +406,26 @@ __global__ void __launch_bounds__(256, 2) k_dw_bwd_img(const f32x4* __restrict__
     }
     return v;
   };
+  const bool left = x0 > 0, right = x0 + XL < W_;              // a neighbour column beyond this thread's run exists
   f32x4 win[3][3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) { win[a][1] = zero; win[a][0] = d1_at(a, 0); }
-  f32x4* orow = dt0 + base + img * ipi + y * W_ * C4 + c4;
+  for (int a = 0; a < 3; ++a) {
+    const f32x4 l = d1_at(a, left ? -1 : 0);
+    win[a][1] = left ? l : zero;
+    win[a][0] = d1_at(a, 0);
+  }
+  f32x4* orow = dt0 + base + img * ipi + (y * W_ + x0) * C4 + c4;
 #pragma unroll
-  for (int x = 0; x < W_; ++x) {
+  for (int x = 0; x < XL; ++x) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       win[a][2] = win[a][1]; win[a][1] = win[a][0];
-      win[a][0] = x + 1 < W_ ? d1_at(a, x + 1) : zero;
+      if (x + 1 < XL) win[a][0] = d1_at(a, x + 1);
+      else if (XS == 1) win[a][0] = zero;
+      else { const f32x4 r = d1_at(a, right ? XL : XL - 1); win[a][0] = right ? r : zero; }
     }
     const f32x4 tv = t0q[x % FD];
-    if (x + FD < W_) t0q[x % FD] = t0p[(x + FD) * C4];
+    if (x + FD < XL) t0q[x % FD] = t0p[(x + FD) * C4];
     f32x4 acc = zero;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -433,7 +443,7 @@ __global__ void __launch_bounds__(256, 2) k_dw_bwd_img(const f32x4* __restrict__
   }
   // ---- block reduction of the 10 float4 accumulators over the threads that share c4, one atomic set per block
   __syncthreads();
-  f32x4* red = tile;                                   // 4 * 10 * C4 float4 <= 256 * W_
+  f32x4* red = tile;                                   // 4 * XS * 10 * C4 float4 <= 256 * W_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 10; ++k) {
@@ -446,10 +456,10 @@ __global__ void __launch_bounds__(256, 2) k_dw_bwd_img(const f32x4* __restrict__
   }
   __syncthreads();
   const int64_t slot = (int64_t)(blockIdx.x % nslots) * slot_stride;
-  for (int idx = threadIdx.x; idx < 10 * C4 * 4; idx += 256) {
+  for (int idx = threadIdx.x; idx < 10 * C4 * 4; idx += NTHR) {
     const int q = idx & 3, cc = (idx >> 2) % C4, k = (idx >> 2) / C4;
     float t = 0.f;
-    for (int wv = 0; wv < 4; ++wv) t += red[(wv * 10 + k) * C4 + cc][q];
+    for (int wv = 0; wv < 4 * XS; ++wv) t += red[(wv * 10 + k) * C4 + cc][q];
     atomicAdd((k < 9 ? dW + slot + (int64_t)k * C4 * 4 : db + slot) + cc * 4 + q, t);
   }
 }
@@ -470,8 +480,7 @@ static bool dw_geom(int H, int W, int C, DwGeom* g, size_t* lds) {
 bool dw_uses_img(bool backward, bool mask_in_lsb, int B, int H, int W, int C) {
   if (!dw_img_shape(B, H, W, C)) return false;
   if (!backward) return true;
-  // (16 wide x 64 channels stays on the ring kernel: same 33 us, and the image kernel needs ~56 spilled registers there)
-  return mask_in_lsb && !(W == 16 && C == 64) && 40 * (C / 4) <= 256 * W;
+  return mask_in_lsb && (W == 16 ? 80 : 40) * (C / 4) <= 256 * W;   // the reduction scratch (waves x 10 x C4 float4) fits the tile
 }
 
 // t1 = relu(dw(t0) + b) and gap = mean_hw(t1) in one pass.  false = shape not covered.
@@ -514,12 +523,13 @@ bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, con
     const float inv = 1.0f / (float)(H * W);
 #define MVAE_DWB(W_)                                                                                                  \
   do {                                                                                                                \
-    if (C == 64) hipLaunchKernelGGL((k_dw_bwd_img<W_, 16>), grid, dim3(256), bytes, s, (const f32x4*)dt2,            \
+    constexpr int XS = W_ == 16 ? 2 : 1;                    /* 16-wide rows: two threads per row, 512 per block */    \
+    if (C == 64) hipLaunchKernelGGL((k_dw_bwd_img<W_, 16, XS>), grid, dim3(256 * XS), bytes, s, (const f32x4*)dt2,   \
                                     (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap,       \
                                     (f32x4*)dt0, sl.at(dW), sl.at(db), H, inv, sl.count(), sl.stride);               \
-    else hipLaunchKernelGGL((k_dw_bwd_img<W_, 8>), grid, dim3(256), bytes, s, (const f32x4*)dt2, (const f32x4*)t0,   \
-                            (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0, sl.at(dW),         \
-                            sl.at(db), H, inv, sl.count(), sl.stride);                                               \
+    else hipLaunchKernelGGL((k_dw_bwd_img<W_, 8, XS>), grid, dim3(256 * XS), bytes, s, (const f32x4*)dt2,            \
+                            (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0,  \
+                            sl.at(dW), sl.at(db), H, inv, sl.count(), sl.stride);                                    \
   } while (0)
     if (W == 16) MVAE_DWB(16); else if (W == 8) MVAE_DWB(8); else MVAE_DWB(4);
 #undef MVAE_DWB
