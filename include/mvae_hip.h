@@ -132,6 +132,20 @@ int mvae_reg_loss(mvae_handle* h, float* out_dev, void* stream);
 /* decoder model (multiscale_vae.py:247-257): z [B,sum z] -> recon [B,H,W,C], inference mode. */
 int mvae_decode(mvae_handle* h, const float* z, int32_t batch, float* recon, void* stream);
 
+/* ---- stand-alone Laplacian pyramid.  Replaces the Keras models built by
+ *      mvae/layer_blocks.py:23-99 (laplacian_transform_split) and :107-185 (laplacian_transform_merge, trainable=False),
+ *      whose behaviour the reference pins in tests/test_layer_blocks.py:118-190.  Stateless; all pointers are device
+ *      memory except `gauss9` (host: the 3x3 kernel of layer_blocks.gaussian_kernel, row-major) and the pointer arrays.
+ *      split:  x [B,H,W,C] in [min,max] -> out[i] [B,H/2^i,W/2^i,C]: level i < levels-1 holds n_i - up2(n_{i+1}), the
+ *              last level holds n_{levels-1}; n_0 = normalised x, n_{i+1} = (G (*) n_i)[::2, ::2].
+ *              work: >= B*H*W*C*4/3 floats.       H, W must be multiples of 2^(levels-1).
+ *      merge:  in[i] as produced by split -> out [B,H,W,C] = clip(denormalise(sum)), work: >= 2*B*H*W*C floats. ---- */
+int mvae_laplacian_split(int32_t device, const float* x, int32_t batch, int32_t H, int32_t W, int32_t C, int32_t levels,
+                         float min_value, float max_value, const float* gauss9, float* const* out, float* work,
+                         void* stream);
+int mvae_laplacian_merge(int32_t device, const float* const* in, int32_t batch, int32_t H, int32_t W, int32_t C,
+                         int32_t levels, float min_value, float max_value, float* out, float* work, void* stream);
+
 /* ---- diagnostics (process-global): per-launch HIP-event timing on the launch stream, used by bench.py for
  *      the per-kernel roofline line.  report writes a JSON object {tag: {count, ms, bytes, flops}} (algorithmic
  *      bytes / flops summed over the launches), returns its length, and clears the records; it synchronises. ---- */

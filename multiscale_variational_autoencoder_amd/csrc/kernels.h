@@ -33,6 +33,11 @@ void launch_rng_keepmask(float* out, int64_t n, float p_drop, const uint64_t* se
 void launch_prep(const float* x, const float* noise, const float* keep, float* out, int B, int H, int W, int C,
                  float v0, float v1, float noise_std, float keep_scale, hipStream_t s);
 void launch_blur_split(const float* in, float* band, float* down, int B, int H, int W, int C, hipStream_t s);
+// stand-alone Laplacian pyramid level (layer_blocks.py:40-72): down = (G (*) in)[::2, ::2]; diff = in - up2(down)
+// false = shape not covered (C > 8 or >= 2^31 pixels)
+bool launch_lap_level(const float* in, float* diff, float* down, int B, int H, int W, int C, const float* gauss9,
+                      hipStream_t s);
+void launch_denorm_clip(const float* in, float* out, int64_t n, float v0, float v1, hipStream_t s);
 
 // ---- convolutions ----
 // small = act(conv(pre(big)) + bias) + residual

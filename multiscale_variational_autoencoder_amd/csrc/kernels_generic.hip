@@ -177,6 +177,92 @@ void launch_blur_split(const float* in, float* band, float* down, int B, int H, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// stand-alone Laplacian pyramid (layer_blocks.py:23-185): unlike the model's own input transform
+// above, a level here is  down = (G (*) in)[::2, ::2]  and  diff = in - up2(down), with up2 = the x2 bilinear
+// upsample of the merge below -- so merge(split(x)) reproduces x exactly up to rounding.
+// ------------------------------------------------------------------------------------------------
+struct Gauss9 { float w[9]; };
+// one thread per output PIXEL (all C <= 8 channels), 32-bit index arithmetic (pixels < 2^31: launcher): the
+// per-element form spent its time in three 64-bit divisions per float
+template <int C>
+__global__ void __launch_bounds__(256) k_lap_down(const float* __restrict__ in, float* __restrict__ down, unsigned B,
+                                                  unsigned H, unsigned W, Gauss9 g) {
+  const unsigned h = H / 2, w = W / 2, n = B * h * w;
+  for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    const unsigned xo = p % w, q = p / w, yo = q % h, b = q / h;
+    const int x = (int)xo * 2, y = (int)yo * 2;
+    float f[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) f[c] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int yy = y + a - 1;
+      if (yy < 0 || yy >= (int)H) continue;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int xx = x + e - 1;
+        if (xx < 0 || xx >= (int)W) continue;
+        const float* ip = in + ((size_t)(b * H + (unsigned)yy) * W + (unsigned)xx) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) f[c] += g.w[a * 3 + e] * ip[c];
+      }
+    }
+    float* op = down + (size_t)p * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) op[c] = f[c];
+  }
+}
+template <int C>
+__global__ void __launch_bounds__(256) k_lap_diff(const float* __restrict__ in, const float* __restrict__ coarse,
+                                                  float* __restrict__ diff, unsigned B, unsigned H, unsigned W) {
+  const unsigned h = H / 2, w = W / 2, n = B * H * W;
+  for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    const unsigned x = p % W, q = p / W, y = q % H, b = q / H;
+    const unsigned iy = y >> 1, ix = x >> 1;
+    const unsigned y2 = (y & 1) ? min(iy + 1, h - 1) : (iy ? iy - 1 : 0u);
+    const unsigned x2 = (x & 1) ? min(ix + 1, w - 1) : (ix ? ix - 1 : 0u);
+    const float* cp = coarse + (size_t)b * h * w * C;
+    const float *p00 = cp + ((size_t)iy * w + ix) * C, *p01 = cp + ((size_t)iy * w + x2) * C;
+    const float *p10 = cp + ((size_t)y2 * w + ix) * C, *p11 = cp + ((size_t)y2 * w + x2) * C;
+    const float* ip = in + (size_t)p * C;
+    float* op = diff + (size_t)p * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float up = 0.75f * (0.75f * p00[c] + 0.25f * p01[c]) + 0.25f * (0.75f * p10[c] + 0.25f * p11[c]);   // as k_upsample_add
+      op[c] = ip[c] - up;
+    }
+  }
+}
+__global__ void k_denorm_clip(const float* __restrict__ in, float* __restrict__ out, int64_t n, float v0, float v1) {
+  GRID_STRIDE(i, n) {
+    float v = (in[i] + 1.0f) * (v1 - v0) * 0.5f + v0;
+    out[i] = fminf(fmaxf(v, v0), v1);
+  }
+}
+bool launch_lap_level(const float* in, float* diff, float* down, int B, int H, int W, int C, const float* gauss9,
+                      hipStream_t s) {
+  if (C < 1 || C > 8 || (int64_t)B * H * W >= (1ll << 31)) return false;
+  Gauss9 g;
+  for (int k = 0; k < 9; ++k) g.w[k] = gauss9[k];
+  const int64_t nd = (int64_t)B * (H / 2) * (W / 2), n = (int64_t)B * H * W;
+  const unsigned gd = (unsigned)grid_for(nd), gf = (unsigned)grid_for(n);
+  switch (C) {
+#define MVAE_LAP(C_)                                                                                                  \
+  case C_:                                                                                                            \
+    hipLaunchKernelGGL(k_lap_down<C_>, dim3(gd), dim3(256), 0, s, in, down, (unsigned)B, (unsigned)H, (unsigned)W, g); \
+    hipLaunchKernelGGL(k_lap_diff<C_>, dim3(gf), dim3(256), 0, s, in, (const float*)down, diff, (unsigned)B,           \
+                       (unsigned)H, (unsigned)W);                                                                     \
+    break;
+    MVAE_LAP(1) MVAE_LAP(2) MVAE_LAP(3) MVAE_LAP(4) MVAE_LAP(5) MVAE_LAP(6) MVAE_LAP(7) MVAE_LAP(8)
+#undef MVAE_LAP
+  }
+  return true;
+}
+void launch_denorm_clip(const float* in, float* out, int64_t n, float v0, float v1, hipStream_t s) {
+  hipLaunchKernelGGL(k_denorm_clip, dim3(grid_for(n)), dim3(kBlock), 0, s, in, out, n, v0, v1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic convolutions.  One thread per output element, channel fastest (coalesced weights / stores).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_conv_f(const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,

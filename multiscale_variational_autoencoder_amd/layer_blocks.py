@@ -1,0 +1,140 @@
+"""Stand-alone Laplacian pyramid front / back end on the HIP path -- the reference's
+`mvae.layer_blocks.laplacian_transform_split` / `laplacian_transform_merge` (layer_blocks.py:23-99, 107-185; SURVEY.md
+section 8(f) rank 3).  Same factory signatures; the returned objects are callable like the Keras models the reference
+returns (`model(x)` / `model.predict(x)`), take / return NHWC float arrays and run `mvae_laplacian_split` /
+`mvae_laplacian_merge` of libmvae_hip.so on `cuda:0`.  There is no CPU fallback.
+
+Not built: `laplacian_transform_merge(trainable=True)` (the conv-mixing variant, layer_blocks.py:147-170): it owns
+trainable weights and belongs with a training graph this build does not have for it."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+DEFAULT_GAUSSIAN_XY_MAX = (1, 1)          # layer_blocks.py:16
+DEFAULT_GAUSSIAN_KERNEL_SIZE = (3, 3)     # layer_blocks.py:17
+
+
+def gaussian_kernel(size, nsig):
+    """layer_blocks.py:980-1002: exp(-d^2/2) sampled on linspace(-nsig, nsig, size), normalised to sum 1."""
+    if len(nsig) != 2 or len(size) != 2:
+        raise AssertionError("size and nsig must have two elements")
+    k1 = [np.linspace(-abs(nsig[i]), abs(nsig[i]), size[i], endpoint=True) for i in range(2)]
+    x, y = np.meshgrid(k1[0], k1[1])
+    g = np.exp(-(x * x + y * y) / 2.0)
+    return g / g.sum()
+
+
+def _check_dims(dims, levels):
+    h, w = int(dims[0]), int(dims[1])
+    if levels < 1:
+        raise ValueError("levels should be >= 1")
+    if h % (1 << (levels - 1)) or w % (1 << (levels - 1)):
+        # the reference fails here too: Subtract() of tensors whose shapes differ after MaxPool / UpSampling2D
+        raise ValueError("height and width must be multiples of 2^(levels-1)")
+
+
+class _HipModel:
+    def __init__(self, name, device):
+        self.name = name
+        self._device = int(device)
+        self._lib = _abi.load_library()
+
+    def _torch(self):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("the HIP path needs a GPU (cuda:%d); there is no CPU fallback" % self._device)
+        return torch, torch.device("cuda", self._device)
+
+    def predict(self, x, batch_size=None):
+        return self(x)
+
+
+class LaplacianSplit(_HipModel):
+    def __init__(self, input_dims, levels, name, min_value, max_value, gaussian_xy_max, gaussian_kernel_size, device=0):
+        super().__init__(name, device)
+        if tuple(gaussian_kernel_size) != (3, 3):
+            raise ValueError("the HIP kernel implements the 3x3 Gaussian (the reference's default)")
+        self.input_dims = tuple(int(d) for d in input_dims)
+        self.levels = int(levels)
+        _check_dims(self.input_dims, self.levels)
+        self.min_value, self.max_value = float(min_value), float(max_value)
+        g = np.ascontiguousarray(gaussian_kernel(gaussian_kernel_size, gaussian_xy_max), dtype=np.float32)
+        self._gauss = (C.c_float * 9)(*g.ravel())
+
+    def __call__(self, x):
+        torch, dev = self._torch()
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+        if x.ndim != 4 or tuple(x.shape[1:]) != self.input_dims:
+            raise ValueError("expected input of shape [B, %d, %d, %d]" % self.input_dims)
+        b, h, w, c = x.shape
+        if b == 0:
+            return [np.zeros((0, h >> i, w >> i, c), np.float32) for i in range(self.levels)]
+        xd = torch.from_numpy(x).to(dev)
+        outs = [torch.empty((b, h >> i, w >> i, c), dtype=torch.float32, device=dev) for i in range(self.levels)]
+        work = torch.empty((b * h * w * c * 4) // 3 + 16, dtype=torch.float32, device=dev)
+        ptrs = (C.c_void_p * self.levels)(*[o.data_ptr() for o in outs])
+        rc = self._lib.mvae_laplacian_split(self._device, C.c_void_p(xd.data_ptr()), b, h, w, c, self.levels,
+                                            self.min_value, self.max_value, self._gauss, ptrs,
+                                            C.c_void_p(work.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != _abi.MVAE_OK:
+            raise RuntimeError("mvae_laplacian_split failed (%d)" % rc)
+        torch.cuda.synchronize(dev)
+        return [o.cpu().numpy() for o in outs]
+
+
+class LaplacianMerge(_HipModel):
+    def __init__(self, input_dims, levels, name, min_value, max_value, device=0):
+        super().__init__(name, device)
+        self.levels = int(levels)
+        self.input_dims = [tuple(int(d) for d in dims) for dims in input_dims][:self.levels]
+        if len(self.input_dims) != self.levels:
+            raise ValueError("input_dims must list one shape per level")
+        _check_dims(self.input_dims[0], self.levels)
+        h, w, c = self.input_dims[0]
+        for i, dims in enumerate(self.input_dims):
+            if dims != (h >> i, w >> i, c):
+                raise ValueError("level %d should have shape %s" % (i, (h >> i, w >> i, c)))
+        self.min_value, self.max_value = float(min_value), float(max_value)
+
+    def __call__(self, xs):
+        torch, dev = self._torch()
+        xs = [np.ascontiguousarray(np.asarray(x, dtype=np.float32)) for x in xs]
+        if len(xs) != self.levels:
+            raise ValueError("expected %d inputs" % self.levels)
+        b = xs[0].shape[0]
+        for x, dims in zip(xs, self.input_dims):
+            if x.ndim != 4 or x.shape[0] != b or tuple(x.shape[1:]) != dims:
+                raise ValueError("expected inputs of shapes [B, *%s]" % (self.input_dims,))
+        h, w, c = self.input_dims[0]
+        if b == 0:
+            return np.zeros((0, h, w, c), np.float32)
+        ds = [torch.from_numpy(x).to(dev) for x in xs]
+        out = torch.empty((b, h, w, c), dtype=torch.float32, device=dev)
+        work = torch.empty(2 * b * h * w * c, dtype=torch.float32, device=dev)
+        ptrs = (C.c_void_p * self.levels)(*[d.data_ptr() for d in ds])
+        rc = self._lib.mvae_laplacian_merge(self._device, ptrs, b, h, w, c, self.levels, self.min_value,
+                                            self.max_value, C.c_void_p(out.data_ptr()), C.c_void_p(work.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != _abi.MVAE_OK:
+            raise RuntimeError("mvae_laplacian_merge failed (%d)" % rc)
+        torch.cuda.synchronize(dev)
+        return out.cpu().numpy()
+
+
+def laplacian_transform_split(input_dims, levels, name=None, min_value=0.0, max_value=255.0,
+                              gaussian_xy_max=DEFAULT_GAUSSIAN_XY_MAX,
+                              gaussian_kernel_size=DEFAULT_GAUSSIAN_KERNEL_SIZE):
+    """layer_blocks.py:23-99: normalise to [-1, 1], then `levels` Laplacian levels (finest first)."""
+    return LaplacianSplit(input_dims, levels, name, min_value, max_value, gaussian_xy_max, gaussian_kernel_size)
+
+
+def laplacian_transform_merge(input_dims, levels, name=None, min_value=0.0, max_value=255.0, trainable=False,
+                              filters=32, activation="relu", kernel_regularizer="l1",
+                              kernel_initializer="glorot_uniform"):
+    """layer_blocks.py:107-185 with trainable=False: upsample-and-add from the coarsest level, denormalise, clip."""
+    if trainable:
+        raise NotImplementedError("laplacian_transform_merge(trainable=True) is not built (see the module docstring)")
+    return LaplacianMerge(input_dims, levels, name, min_value, max_value)
