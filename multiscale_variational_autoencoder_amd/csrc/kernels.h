@@ -35,9 +35,13 @@ void launch_prep(const float* x, const float* noise, const float* keep, float* o
 void launch_blur_split(const float* in, float* band, float* down, int B, int H, int W, int C, hipStream_t s);
 // stand-alone Laplacian pyramid level (layer_blocks.py:40-72): down = (G (*) in)[::2, ::2]; diff = in - up2(down)
 // false = shape not covered (C > 8 or >= 2^31 pixels)
+// normalise: `in` is the raw image in [v0, v1], normalised to [-1, 1] as it is read
 bool launch_lap_level(const float* in, float* diff, float* down, int B, int H, int W, int C, const float* gauss9,
-                      hipStream_t s);
+                      bool normalise, float v0, float v1, hipStream_t s);
 void launch_denorm_clip(const float* in, float* out, int64_t n, float v0, float v1, hipStream_t s);
+// out = up2(coarse) + fine; final_level: out = clip(denormalise(.)) instead (layer_blocks.py:123-131, 137-171)
+bool launch_lap_merge(const float* coarse, const float* fine, float* out, int B, int H, int W, int C, bool final_level,
+                      float v0, float v1, hipStream_t s);
 
 // ---- convolutions ----
 // small = act(conv(pre(big)) + bias) + residual

@@ -170,9 +170,56 @@ __global__ void k_blur_split(const float* __restrict__ in, float* __restrict__ b
     }
   }
 }
+// the same with one thread per pixel (all C <= 4 channels) and 32-bit index arithmetic
+template <int C>
+__global__ void __launch_bounds__(256) k_blur_split_px(const float* __restrict__ in, float* __restrict__ band,
+                                                       float* __restrict__ down, unsigned B, unsigned H, unsigned W,
+                                                       unsigned DH, unsigned DW) {
+  const unsigned n = B * H * W;
+  for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    const unsigned xw = p % W, q = p / W, yh = q % H, b = q / H;
+    float f[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) f[c] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int yy = (int)yh + a - 1;
+      if (yy < 0 || yy >= (int)H) continue;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int xx = (int)xw + e - 1;
+        if (xx < 0 || xx >= (int)W) continue;
+        const float* ip = in + ((size_t)(b * H + (unsigned)yy) * W + (unsigned)xx) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) f[c] += c_gauss[a * 3 + e] * ip[c];
+      }
+    }
+    const float* ip = in + (size_t)p * C;
+    float* bp = band + (size_t)p * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) bp[c] = ip[c] - f[c];
+    if (!(yh & 1) && !(xw & 1) && (yh >> 1) < DH && (xw >> 1) < DW) {
+      float* dp = down + ((size_t)(b * DH + (yh >> 1)) * DW + (xw >> 1)) * C;
+#pragma unroll
+      for (int c = 0; c < C; ++c) dp[c] = f[c];
+    }
+  }
+}
 void launch_blur_split(const float* in, float* band, float* down, int B, int H, int W, int C, hipStream_t s) {
   ProfScope ps("pyramid", (double)(10.0*B*H*W*C), 0.0, s);
   int64_t n = (int64_t)B * H * W * C;
+  if (C >= 1 && C <= 4 && (int64_t)B * H * W < (1ll << 31)) {
+    const unsigned gf = (unsigned)grid_for((int64_t)B * H * W);
+    switch (C) {
+#define MVAE_BS(C_)                                                                                                   \
+  case C_:                                                                                                            \
+    hipLaunchKernelGGL(k_blur_split_px<C_>, dim3(gf), dim3(256), 0, s, in, band, down, (unsigned)B, (unsigned)H,      \
+                       (unsigned)W, (unsigned)(H / 2), (unsigned)(W / 2));                                            \
+    return;
+      MVAE_BS(1) MVAE_BS(2) MVAE_BS(3) MVAE_BS(4)
+#undef MVAE_BS
+    }
+  }
   hipLaunchKernelGGL(k_blur_split, dim3(grid_for(n)), dim3(kBlock), 0, s, in, band, down, B, H, W, C, H / 2, W / 2);
 }
 
@@ -184,9 +231,10 @@ void launch_blur_split(const float* in, float* band, float* down, int B, int H, 
 struct Gauss9 { float w[9]; };
 // one thread per output PIXEL (all C <= 8 channels), 32-bit index arithmetic (pixels < 2^31: launcher): the
 // per-element form spent its time in three 64-bit divisions per float
-template <int C>
+// NORM: `in` is the raw image, normalised on the fly (v - v0) * k - 1 (level 0: saves writing and re-reading it)
+template <int C, bool NORM>
 __global__ void __launch_bounds__(256) k_lap_down(const float* __restrict__ in, float* __restrict__ down, unsigned B,
-                                                  unsigned H, unsigned W, Gauss9 g) {
+                                                  unsigned H, unsigned W, Gauss9 g, float v0, float k2) {
   const unsigned h = H / 2, w = W / 2, n = B * h * w;
   for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
     const unsigned xo = p % w, q = p / w, yo = q % h, b = q / h;
@@ -204,7 +252,7 @@ __global__ void __launch_bounds__(256) k_lap_down(const float* __restrict__ in, 
         if (xx < 0 || xx >= (int)W) continue;
         const float* ip = in + ((size_t)(b * H + (unsigned)yy) * W + (unsigned)xx) * C;
 #pragma unroll
-        for (int c = 0; c < C; ++c) f[c] += g.w[a * 3 + e] * ip[c];
+        for (int c = 0; c < C; ++c) f[c] += g.w[a * 3 + e] * (NORM ? (ip[c] - v0) * k2 - 1.0f : ip[c]);
       }
     }
     float* op = down + (size_t)p * C;
@@ -212,9 +260,10 @@ __global__ void __launch_bounds__(256) k_lap_down(const float* __restrict__ in, 
     for (int c = 0; c < C; ++c) op[c] = f[c];
   }
 }
-template <int C>
+template <int C, bool NORM>
 __global__ void __launch_bounds__(256) k_lap_diff(const float* __restrict__ in, const float* __restrict__ coarse,
-                                                  float* __restrict__ diff, unsigned B, unsigned H, unsigned W) {
+                                                  float* __restrict__ diff, unsigned B, unsigned H, unsigned W, float v0,
+                                                  float k2) {
   const unsigned h = H / 2, w = W / 2, n = B * H * W;
   for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
     const unsigned x = p % W, q = p / W, y = q % H, b = q / H;
@@ -229,7 +278,7 @@ __global__ void __launch_bounds__(256) k_lap_diff(const float* __restrict__ in, 
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const float up = 0.75f * (0.75f * p00[c] + 0.25f * p01[c]) + 0.25f * (0.75f * p10[c] + 0.25f * p11[c]);   // as k_upsample_add
-      op[c] = ip[c] - up;
+      op[c] = (NORM ? (ip[c] - v0) * k2 - 1.0f : ip[c]) - up;
     }
   }
 }
@@ -239,22 +288,72 @@ __global__ void k_denorm_clip(const float* __restrict__ in, float* __restrict__ 
     out[i] = fminf(fmaxf(v, v0), v1);
   }
 }
+// merge step (layer_blocks.py:137-171): fine_out = up2(coarse) + fine_in; FINAL: only clip(denormalise(.)) is written
+// MODE 0: out = sum;  1 (FINAL): out = clip(denormalise(sum));  2: out = sum and out2 = clip(denormalise(sum))
+template <int C, int MODE>
+__global__ void __launch_bounds__(256) k_lap_merge(const float* __restrict__ coarse, const float* __restrict__ fine,
+                                                   float* __restrict__ out, float* __restrict__ out2, unsigned B,
+                                                   unsigned H, unsigned W, float v0, float v1) {
+  const unsigned h = H / 2, w = W / 2, n = B * H * W;
+  for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    const unsigned x = p % W, q = p / W, y = q % H, b = q / H;
+    const unsigned iy = y >> 1, ix = x >> 1;
+    const unsigned y2 = (y & 1) ? min(iy + 1, h - 1) : (iy ? iy - 1 : 0u);
+    const unsigned x2 = (x & 1) ? min(ix + 1, w - 1) : (ix ? ix - 1 : 0u);
+    const float* cp = coarse + (size_t)b * h * w * C;
+    const float *p00 = cp + ((size_t)iy * w + ix) * C, *p01 = cp + ((size_t)iy * w + x2) * C;
+    const float *p10 = cp + ((size_t)y2 * w + ix) * C, *p11 = cp + ((size_t)y2 * w + x2) * C;
+    const float* ip = fine + (size_t)p * C;
+    float* op = out + (size_t)p * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float up = 0.75f * (0.75f * p00[c] + 0.25f * p01[c]) + 0.25f * (0.75f * p10[c] + 0.25f * p11[c]);
+      const float m = up + ip[c];
+      const float v = fminf(fmaxf((m + 1.0f) * (v1 - v0) * 0.5f + v0, v0), v1);
+      if (MODE == 1) op[c] = v;
+      else op[c] = m;
+      if (MODE == 2) out2[(size_t)p * C + c] = v;
+    }
+  }
+}
+bool launch_lap_merge(const float* coarse, const float* fine, float* out, int B, int H, int W, int C, bool final_level,
+                      float v0, float v1, hipStream_t s) {
+  if (C < 1 || C > 8 || (int64_t)B * H * W >= (1ll << 31)) return false;
+  const unsigned gf = (unsigned)grid_for((int64_t)B * H * W);
+  switch (C) {
+#define MVAE_LM(C_)                                                                                                   \
+  case C_:                                                                                                            \
+    if (final_level) hipLaunchKernelGGL((k_lap_merge<C_, 1>), dim3(gf), dim3(256), 0, s, coarse, fine, out,           \
+                                        (float*)nullptr, (unsigned)B, (unsigned)H, (unsigned)W, v0, v1);              \
+    else hipLaunchKernelGGL((k_lap_merge<C_, 0>), dim3(gf), dim3(256), 0, s, coarse, fine, out, (float*)nullptr,      \
+                            (unsigned)B, (unsigned)H, (unsigned)W, v0, v1);                                           \
+    break;
+    MVAE_LM(1) MVAE_LM(2) MVAE_LM(3) MVAE_LM(4) MVAE_LM(5) MVAE_LM(6) MVAE_LM(7) MVAE_LM(8)
+#undef MVAE_LM
+  }
+  return true;
+}
 bool launch_lap_level(const float* in, float* diff, float* down, int B, int H, int W, int C, const float* gauss9,
-                      hipStream_t s) {
+                      bool normalise, float v0, float v1, hipStream_t s) {
   if (C < 1 || C > 8 || (int64_t)B * H * W >= (1ll << 31)) return false;
   Gauss9 g;
   for (int k = 0; k < 9; ++k) g.w[k] = gauss9[k];
   const int64_t nd = (int64_t)B * (H / 2) * (W / 2), n = (int64_t)B * H * W;
   const unsigned gd = (unsigned)grid_for(nd), gf = (unsigned)grid_for(n);
+  const float k2 = 2.0f / (v1 - v0);
   switch (C) {
+#define MVAE_LAP2(C_, N_)                                                                                             \
+    hipLaunchKernelGGL((k_lap_down<C_, N_>), dim3(gd), dim3(256), 0, s, in, down, (unsigned)B, (unsigned)H,           \
+                       (unsigned)W, g, v0, k2);                                                                       \
+    hipLaunchKernelGGL((k_lap_diff<C_, N_>), dim3(gf), dim3(256), 0, s, in, (const float*)down, diff, (unsigned)B,    \
+                       (unsigned)H, (unsigned)W, v0, k2);
 #define MVAE_LAP(C_)                                                                                                  \
   case C_:                                                                                                            \
-    hipLaunchKernelGGL(k_lap_down<C_>, dim3(gd), dim3(256), 0, s, in, down, (unsigned)B, (unsigned)H, (unsigned)W, g); \
-    hipLaunchKernelGGL(k_lap_diff<C_>, dim3(gf), dim3(256), 0, s, in, (const float*)down, diff, (unsigned)B,           \
-                       (unsigned)H, (unsigned)W);                                                                     \
+    if (normalise) { MVAE_LAP2(C_, true) } else { MVAE_LAP2(C_, false) }                                              \
     break;
     MVAE_LAP(1) MVAE_LAP(2) MVAE_LAP(3) MVAE_LAP(4) MVAE_LAP(5) MVAE_LAP(6) MVAE_LAP(7) MVAE_LAP(8)
 #undef MVAE_LAP
+#undef MVAE_LAP2
   }
   return true;
 }
@@ -1025,6 +1124,20 @@ void launch_upsample_add(const float* coarse, const float* fine_in, float* fine_
                          int W, int C, float v0, float v1, hipStream_t s) {
   ProfScope ps("merge", (double)(12.0*B*H*W*C), 0.0, s);
   int64_t n = (int64_t)B * H * W * C;
+  if (C >= 1 && C <= 4 && (int64_t)B * H * W < (1ll << 31)) {        // one thread per pixel, 32-bit indices (k_lap_merge)
+    const unsigned gf = (unsigned)grid_for((int64_t)B * H * W);
+    switch (C) {
+#define MVAE_UA(C_)                                                                                                   \
+  case C_:                                                                                                            \
+    if (recon) hipLaunchKernelGGL((k_lap_merge<C_, 2>), dim3(gf), dim3(256), 0, s, coarse, fine_in, fine_out, recon,  \
+                                  (unsigned)B, (unsigned)H, (unsigned)W, v0, v1);                                     \
+    else hipLaunchKernelGGL((k_lap_merge<C_, 0>), dim3(gf), dim3(256), 0, s, coarse, fine_in, fine_out,               \
+                            (float*)nullptr, (unsigned)B, (unsigned)H, (unsigned)W, v0, v1);                          \
+    return;
+      MVAE_UA(1) MVAE_UA(2) MVAE_UA(3) MVAE_UA(4)
+#undef MVAE_UA
+    }
+  }
   hipLaunchKernelGGL(k_upsample_add, dim3(grid_for(n)), dim3(kBlock), 0, s, coarse, fine_in, fine_out, recon, B, H, W,
                      C, v0, v1);
 }

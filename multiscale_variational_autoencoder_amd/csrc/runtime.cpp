@@ -1194,17 +1194,20 @@ int mvae_laplacian_split(int32_t device, const float* x, int32_t batch, int32_t 
   if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n0 = (int64_t)batch * H * W * C;
-  // work: the normalised image of each level but the last (level i at offset sum_{j<i} n0 / 4^j); the last level's
-  // normalised image IS its output
-  float* cur = levels == 1 ? out[0] : work;
-  launch_prep(x, nullptr, nullptr, cur, batch, H, W, C, min_value, max_value, 0.f, 1.f, s);
+  // level 0 reads the raw image and normalises on the fly; work holds the normalised image of levels 1 .. levels-2
+  // (the last level's normalised image IS its output)
+  if (levels == 1) {
+    launch_prep(x, nullptr, nullptr, out[0], batch, H, W, C, min_value, max_value, 0.f, 1.f, s);
+    return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
+  }
+  const float* cur = x;
   int h = H, w = W;
   int64_t off = 0;
   for (int i = 0; i + 1 < levels; ++i) {
-    const int64_t n = (int64_t)batch * h * w * C;
-    float* down = i + 2 == levels ? out[levels - 1] : work + off + n;
-    if (!launch_lap_level(cur, out[i], down, batch, h, w, C, gauss9, s)) return MVAE_E_INVALID;
-    off += n;
+    const int64_t nd = (int64_t)batch * (h / 2) * (w / 2) * C;
+    float* down = i + 2 == levels ? out[levels - 1] : work + off;
+    if (!launch_lap_level(cur, out[i], down, batch, h, w, C, gauss9, i == 0, min_value, max_value, s)) return MVAE_E_INVALID;
+    off += nd;
     cur = down;
     h /= 2; w /= 2;
   }
@@ -1214,7 +1217,7 @@ int mvae_laplacian_split(int32_t device, const float* x, int32_t batch, int32_t 
 
 int mvae_laplacian_merge(int32_t device, const float* const* in, int32_t batch, int32_t H, int32_t W, int32_t C,
                          int32_t levels, float min_value, float max_value, float* out, float* work, void* stream) {
-  if (!in || !out || !work || batch <= 0 || C <= 0 || levels < 1 || levels > MVAE_MAX_LEVELS) return MVAE_E_INVALID;
+  if (!in || !out || !work || batch <= 0 || C <= 0 || C > 8 || levels < 1 || levels > MVAE_MAX_LEVELS) return MVAE_E_INVALID;
   if (H <= 0 || W <= 0 || (H % (1 << (levels - 1))) || (W % (1 << (levels - 1)))) return MVAE_E_INVALID;
   if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1227,8 +1230,8 @@ int mvae_laplacian_merge(int32_t device, const float* const* in, int32_t batch, 
   const float* coarse = in[levels - 1];
   for (int i = levels - 2; i >= 0; --i) {
     const int h = H >> i, w = W >> i;
-    float* dst = work + (i & 1) * n0;
-    launch_upsample_add(coarse, in[i], dst, i == 0 ? out : nullptr, batch, h, w, C, min_value, max_value, s);
+    float* dst = i == 0 ? out : work + (i & 1) * n0;
+    if (!launch_lap_merge(coarse, in[i], dst, batch, h, w, C, i == 0, min_value, max_value, s)) return MVAE_E_INVALID;
     coarse = dst;
   }
   return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
