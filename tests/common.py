@@ -32,6 +32,9 @@ CONFIGS = {
     "c32nb": dict(input_dims=(32, 32, 3), z_dims=[16, 16, 16], encoder=NB, decoder=NB),
     # BASELINE configs 4-5 shrunk to 64x64 / 5 scales for parity runs (same block structure as C256-nb)
     "c64nb": dict(input_dims=(64, 64, 3), z_dims=[16] * 5, encoder=NB, decoder=NB),
+    # the notebook blocks on a 24 x 40 image: widths 40 / 20 / 10 are not powers of two (the index-division paths of the
+    # tiled conv kernels), 3 x 12 x 20 pixels do not fill the kernels' 128-pixel tiles, 40 columns need two ring strips
+    "nbodd": dict(input_dims=(24, 40, 3), z_dims=[8, 8], encoder=NB, decoder=NB),
     # BASELINE configs 4-5 (C256-nb), full size: 7 scales from 256x256 down to 4x4
     "c256nb": dict(input_dims=(256, 256, 3), z_dims=[16] * 7, encoder=NB, decoder=NB),
 }

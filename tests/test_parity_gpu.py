@@ -48,7 +48,7 @@ def _dump(name, report):
         json.dump(report, f, indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("name,B", [("tiny", 4), ("odd", 3), ("c32def", 4), ("main", 4), ("c32nb", 8), ("c64nb", 2)])
+@pytest.mark.parametrize("name,B", [("tiny", 4), ("odd", 3), ("c32def", 4), ("main", 4), ("c32nb", 8), ("c64nb", 2), ("nbodd", 3)])
 def test_forward_backward_parity(name, B):
     io, oc, orc, res, G, inter, eng, out = _run_pair(name, B)
     rep = {}
