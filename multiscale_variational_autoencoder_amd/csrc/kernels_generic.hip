@@ -1321,17 +1321,28 @@ void launch_opt_prepare(const float* w, float* g, const ChunkDesc* chunks, int n
   ProfScope ps("optimizer", (double)(0.0), 0.0, s);
   hipLaunchKernelGGL(k_opt_prepare, dim3(nchunks), dim3(256), 0, s, w, g, chunks, norms, grad_scale);
 }
+// ||g||^2 of every tensor: the block of a tensor's FIRST chunk adds up the tensor's per-chunk partials in a fixed
+// order (thread t takes partials t, t + 256, ...; block_sum is a fixed tree) -> tnorm[first chunk].  No float atomics:
+// the clip factor, and with it the parameter update, is bit-identical on every replica of a data-parallel run.  (Every
+// block of k_opt_apply used to walk all `count` partials itself: 4096 dependent loads per block for the 8 M-element
+// Dense weights of the 256x256 configuration, 617 us per launch.)
+__global__ void __launch_bounds__(256) k_opt_tnorm(const ChunkDesc* __restrict__ chunks, const float* __restrict__ norms,
+                                                   float* __restrict__ tnorm) {
+  __shared__ float sh[16];
+  const ChunkDesc cd = chunks[blockIdx.x];
+  if (cd.first != (int)blockIdx.x) return;             // block-uniform
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < cd.count; j += 256) acc += norms[cd.first + j];
+  const float t = block_sum(acc, sh);
+  if (threadIdx.x == 0) tnorm[blockIdx.x] = t;
+}
 __global__ void __launch_bounds__(256) k_opt_apply(float* __restrict__ w, const float* __restrict__ g,
                                                    float* __restrict__ a, const ChunkDesc* __restrict__ chunks,
-                                                   const float* __restrict__ norms, float lr, float clip_norm) {
+                                                   const float* __restrict__ tnorm, float lr, float clip_norm) {
   ChunkDesc cd = chunks[blockIdx.x];
   float f = 1.0f;
   if (clip_norm > 0.f) {
-    // ||g||^2 of the whole tensor: its chunks' partial sums in a FIXED order (no float atomics: the clip factor, and with
-    // it the parameter update, is bit-identical on every replica of a data-parallel run)
-    float sq = 0.f;
-    for (int j = 0; j < cd.count; ++j) sq += norms[cd.first + j];
-    const float nrm = sqrtf(sq);
+    const float nrm = sqrtf(tnorm[cd.first]);
     f = clip_norm / fmaxf(nrm, clip_norm);       // tf.clip_by_norm
   }
   for (int i = threadIdx.x; i < cd.len; i += blockDim.x) {
@@ -1345,7 +1356,9 @@ __global__ void __launch_bounds__(256) k_opt_apply(float* __restrict__ w, const 
 void launch_opt_apply(float* w, const float* g, float* a, const ChunkDesc* chunks, int nchunks, const float* norms,
                       float lr, float clip_norm, hipStream_t s) {
   ProfScope ps("optimizer", (double)(0.0), 0.0, s);
-  hipLaunchKernelGGL(k_opt_apply, dim3(nchunks), dim3(256), 0, s, w, g, a, chunks, norms, lr, clip_norm);
+  float* tnorm = const_cast<float*>(norms) + nchunks;           // second half of the norms buffer (runtime: 2 x nchunks)
+  if (clip_norm > 0.f) hipLaunchKernelGGL(k_opt_tnorm, dim3(nchunks), dim3(256), 0, s, chunks, norms, tnorm);
+  hipLaunchKernelGGL(k_opt_apply, dim3(nchunks), dim3(256), 0, s, w, g, a, chunks, (const float*)tnorm, lr, clip_norm);
 }
 __global__ void __launch_bounds__(256) k_reg_loss(const float* __restrict__ w, const ChunkDesc* __restrict__ chunks,
                                                   float* __restrict__ out) {

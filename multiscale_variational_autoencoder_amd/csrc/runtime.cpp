@@ -377,7 +377,7 @@ int build_plan(mvae_handle* h) {
   h->off_chunks = b.ws_alloc((int64_t)(h->chunks.size() * sizeof(ChunkDesc) + 3) / 4);
   h->off_slot_chunks = b.ws_alloc((int64_t)(h->slot_chunks.size() * sizeof(ChunkDesc) + 3) / 4);
   h->off_sdescs = b.ws_alloc((int64_t)(h->sdescs.size() * sizeof(StateDesc) + 3) / 4);
-  h->off_norms = b.ws_alloc((int64_t)h->chunks.size());          // one partial ||g||^2 per chunk
+  h->off_norms = b.ws_alloc(2 * (int64_t)h->chunks.size());      // one partial ||g||^2 per chunk, then one total per tensor
   h->off_seed = b.ws_alloc(kAlign);
   h->off_slots = b.ws_alloc((int64_t)kGradSlots * h->P);
   h->ws_floats = b.wcur;
