@@ -2,7 +2,7 @@
 // :402-406 decoder Dense): skinny products, K or N = z <= 32 against 512 .. 524288.
 //   k_skinny_mfma   out[b, j] += sum_k A[b,k] * Wcol_j[k]     split-K over waves on v_mfma_f32_32x32x2_f32;
 //                   mu and log_var are produced by ONE launch (their weights are two column blocks of the B operand)
-//   k_dense_bwd2    dflat[b,k] = sum_j dmu[b,j] Wmu[k,j] + dlv[b,j] Wlv[k,j]   (one pass, 4 batch rows per block)
+//   k_dense_bwd2    dflat[b,k] = sum_j dmu[b,j] Wmu[k,j] + dlv[b,j] Wlv[k,j]   (one pass, 16 batch rows per block)
 //   k_dense_expand  out[b,n]   = bias[n] + sum_k z[b,k] W[k,n]                  (16-byte stores, 4 batch rows per block)
 //   k_outer_wide2   dWmu[k,j], dWlv[k,j] += sum_b flat[b,k] * {dmu,dlv}[b,j]    (flat is read once for both)
 #include "kernels.h"
@@ -129,12 +129,16 @@ __global__ void __launch_bounds__(256) k_skinny_mfma256(const float* __restrict_
   }
 }
 
+// RB batch rows per block: the two [K, Z] weight matrices are re-read B / RB times (4 rows per block made that 16 times,
+// 1 GB of L2 traffic, for the 524288 x 16 heads of the 256 x 256 configuration: 268 us)
+constexpr int kDflatRows = 16;
 __global__ void __launch_bounds__(256) k_dense_bwd2(const float* __restrict__ g1, const float* __restrict__ g2,
                                                     const float* __restrict__ W1, const float* __restrict__ W2,
                                                     float* __restrict__ out, int B, int K, int Z) {
-  __shared__ float sg[4][64];
-  const int b0 = blockIdx.y * 4;
-  for (int t = threadIdx.x; t < 4 * 2 * Z; t += 256) {
+  constexpr int RB = kDflatRows;
+  __shared__ float sg[RB][64];
+  const int b0 = blockIdx.y * RB;
+  for (int t = threadIdx.x; t < RB * 2 * Z; t += 256) {
     const int r = t / (2 * Z), j = t % (2 * Z);
     const int b = b0 + r;
     sg[r][j] = b < B ? (j < Z ? g1[(int64_t)b * Z + j] : g2[(int64_t)b * Z + j - Z]) : 0.f;
@@ -142,16 +146,30 @@ __global__ void __launch_bounds__(256) k_dense_bwd2(const float* __restrict__ g1
   __syncthreads();
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= K) return;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) acc[r] = 0.f;
   const float* w1 = W1 + (int64_t)k * Z;
   const float* w2 = W2 + (int64_t)k * Z;
-  for (int j = 0; j < Z; ++j) {
-    const float a = w1[j], c = w2[j];
+  if (Z == 16) {                        // the notebook's z: both weight rows as one batch of 16-byte loads
+    f32x4 a4[4], c4[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += sg[r][j] * a + sg[r][Z + j] * c;
+    for (int q = 0; q < 4; ++q) { a4[q] = reinterpret_cast<const f32x4*>(w1)[q]; c4[q] = reinterpret_cast<const f32x4*>(w2)[q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] += sg[r][q * 4 + e] * a4[q][e] + sg[r][16 + q * 4 + e] * c4[q][e];
+  } else {
+    for (int j = 0; j < Z; ++j) {
+      const float a = w1[j], c = w2[j];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) acc[r] += sg[r][j] * a + sg[r][Z + j] * c;
+    }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < RB; ++r)
     if (b0 + r < B) out[(int64_t)(b0 + r) * K + k] = acc[r];
 }
 
@@ -380,7 +398,7 @@ bool launch_dense_dz(const float* dy, const float* W, float* dz, int B, int Z, i
 bool launch_dense_dflat(const float* dmu, const float* dlv, const float* Wmu, const float* Wlv, float* out, int B, int K,
                         int Z, hipStream_t s) {
   if (2 * Z > 64) return false;
-  hipLaunchKernelGGL(k_dense_bwd2, dim3((K + 255) / 256, (B + 3) / 4), dim3(256), 0, s, dmu, dlv, Wmu, Wlv, out, B, K, Z);
+  hipLaunchKernelGGL(k_dense_bwd2, dim3((K + 255) / 256, (B + kDflatRows - 1) / kDflatRows), dim3(256), 0, s, dmu, dlv, Wmu, Wlv, out, B, K, Z);
   return true;
 }
 bool launch_dense_expand(const float* z, const float* W, const float* bias, float* out, int B, int Z, int N,
