@@ -35,16 +35,17 @@ WORKLOADS = {
                    decoder={"filters": [32], "kernel_size": [(3, 3)], "strides": [(1, 1)]}, batch=512,
                    A=592657, P=2138313, F=19.9e6),
     "c256nb": dict(input_dims=(256, 256, 3), z_dims=[16] * 7, encoder=NB, decoder=NB, batch=64,
-                   A=176231857, P=36045205, F=13444.5e6),
+                   A=176231857, P=36045205, F=13444.5e6, dtype="bf16"),
 }
 HBM_PEAK = 8.0e12        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
 FP32_PEAK = 157.3e12     # fp32 vector = f32-input MFMA rate
+BF16_PEAK = 2.5e15       # dense bf16 MFMA
 
 
-def algorithmic_bytes_per_step(w, B):
-    """SURVEY.md 8(d): B*5*A*4 + 7*P*4 (fp32 activations; fwd write+read, bwd re-read, grad write+read;
-    weight read x2, dW write+read, accumulator r/w, weight write)."""
-    return B * 5 * w["A"] * 4 + 7 * w["P"] * 4
+def algorithmic_bytes_per_step(w, B, act="f32"):
+    """B*5*A*dt + 7*P*4 (dt = 4 fp32 / 2 bf16 activations; fwd write+read, bwd re-read, grad
+    write+read; weight read x2, dW write+read, accumulator r/w, weight write -- parameters stay fp32)."""
+    return B * 5 * w["A"] * (2 if act == "bf16" else 4) + 7 * w["P"] * 4
 
 
 def cpu_baseline(wname, seconds=20.0):
@@ -59,7 +60,7 @@ def cpu_baseline(wname, seconds=20.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))     # a 1-GPU box grants a 16-core share; more threads only oversubscribe it
+    cores = max(1, cores)              # every core this process may run on (a 1-GPU box grants a 16-core share)
     torch.set_num_threads(cores)
     oc = OracleConfig(w["input_dims"], w["z_dims"], encoder=w["encoder"], decoder=w["decoder"])
     P, S = param_table(oc)
@@ -81,20 +82,61 @@ def cpu_baseline(wname, seconds=20.0):
         step(); n += 1
         sys.stderr.write("cpu_baseline step %d  %.1fs\n" % (n, time.time() - t0)); sys.stderr.flush()
     dt = time.time() - t0
-    return dict(value=Bc * n / dt, unit="images/sec", cores=cores, kind="port",
-                sample="%d train steps of batch %d (%s, fp32, torch-CPU restatement oracle/mvae_oracle.py, %d threads)"
-                       % (n, Bc, wname, cores))
+    return dict(value=Bc * n / dt, unit="images/sec", cores=cores, kind="port", cpu_model=cpu_model(),
+                sample="%d train steps of batch %d (%s, fp32, torch-CPU restatement oracle/mvae_oracle.py -- not Keras --, "
+                       "%d threads on %s)" % (n, Bc, wname, cores, cpu_model()))
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def timed_steps(eng, step, steps, torch, dist, world):
+    """EXACTLY `steps` steps between barrier + synchronize on both sides (the driver's contract: wall clock, max over
+    ranks) with a HIP event recorded on the engine's stream after every step (hipEvent timing, median)."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs[0].record(eng.stream)
+    for i in range(steps):
+        step(i)
+        evs[i + 1].record(eng.stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, per
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)        # SURVEY 8(d): >= 50 timed steps unless the caller says otherwise
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c32nb", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"], help="activation storage (default: the workload's)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="one-GPU run through the RCCL all-reduce branch (a world-size-1 nccl group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -111,11 +153,12 @@ def main():
     if rehearse:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if rehearse:
             dist.init_process_group(rehearse, rank=rank, world_size=world)
-        else:
+        else:          # any RCCL error raises and ends the process with a non-zero exit code
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from multiscale_variational_autoencoder_amd.engine import Engine
@@ -123,37 +166,37 @@ def main():
     from multiscale_variational_autoencoder_amd import _abi
     w = WORKLOADS[args.workload]
     B = args.batch or w["batch"]
-    eng = Engine(w["input_dims"], w["z_dims"], w["encoder"], w["decoder"], 0.0, 255.0, 0.01, B).bind(local)
+    act = args.dtype or w.get("dtype", "f32")
+    eng = Engine(w["input_dims"], w["z_dims"], w["encoder"], w["decoder"], 0.0, 255.0, 0.01, B, act_dtype=act).bind(local)
     eng.set_params(init_params(eng.param_table, 42))          # identical replicas on every rank
     H, Wd, C = w["input_dims"]
     x = eng.to_device(np.random.default_rng(1234 + rank).uniform(0, 255, (B, H, Wd, C)))
     lr, rf, kf, clip = 1e-3, 1000.0, 10.0, 1.0
+    coll_timing = []
+    collective = eng.collective_active(args.force_collective)
 
-    def step(i):
-        eng.train_step(x, lr, rf, kf, clip, seed=1000 + i)
+    def step(i):        # rank-dependent device-RNG seed: replicas draw independent noise / dropout / epsilon
+        eng.train_step(x, lr, rf, kf, clip, seed=(1000 + i) ^ (rank * 0x9E3779B97F4A7C15 & (2 ** 62 - 1)),
+                       force_collective=args.force_collective, timing=coll_timing if collective else None)
 
     for i in range(max(args.warmup, 1)):     # the first call of each signature captures its hipGraph
         step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    del coll_timing[:]
+    dt, per_step = timed_steps(eng, lambda i: step(args.warmup + i), args.steps, torch, dist, world)
+    coll = None
+    if collective and coll_timing:
+        ar_ms = float(np.median([a.elapsed_time(b) for a, b in coll_timing]))
+        nbytes = eng.R * 4
+        n = max(world, 1)
+        coll = {"collective_bytes": nbytes, "allreduce_ms_median": ar_ms,
+                "algbw_GBps": nbytes / (ar_ms * 1e-3) / 1e9,
+                "busbw_GBps": nbytes / (ar_ms * 1e-3) / 1e9 * (2.0 * (n - 1) / n), "backend": rehearse or "nccl(RCCL)",
+                "world": world}
     m = eng.metrics()
     finite = bool(np.isfinite(m["r_exp"]) and np.isfinite(m["vae_kl_loss"]))
     # "also report forward+backward+ELBO without the optimiser" (secondary number, single GPU only)
     fb_ms = None
+    secondary = {}
     if world == 1:
         nfb = max(min(args.steps, 10), 1)
         for i in range(2):
@@ -187,49 +230,79 @@ def main():
         d = kernels[dom]
         bytes_per_launch = d["bytes"] / d["count"]
         dur = d["ms"] * 1e-3 / d["count"]
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this
-        # same command, FETCH doubled per MI355X_MICROARCH.md; tools/pmc_traffic.py), when that kernel was profiled
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            traffic = pmc.get("mvae::" + dom, {}).get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
+        # HBM bytes per launch: NOT measured in this run -- taken from the committed rocprofv3 PMC passes (separate
+        # FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH doubled per MI355X_MICROARCH.md; tools/pmc_traffic.py)
+        traffic, traffic_source = None, None
+        for cand in ("round2_pmc_traffic_%s.json" % args.workload, "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", cand)) as f:
+                    pmc = json.load(f)
+            except (OSError, ValueError):
+                continue
+            t = pmc.get("mvae::" + dom, pmc.get(dom, {})).get("hbm_bytes_per_launch")
+            if t is not None and (cand.startswith("round2") or args.workload == "c32nb"):
+                traffic, traffic_source = t, "profiles/" + cand + " (separate rocprofv3 --pmc passes, not this run)"
+                break
+        peak_f = BF16_PEAK if act == "bf16" else FP32_PEAK
         roofline = dict(kernel=dom, bound="hbm", achieved=bytes_per_launch / dur / 1e9, peak=HBM_PEAK / 1e9,
                         unit="GB/s", frac=bytes_per_launch / dur / HBM_PEAK, traffic=traffic,
+                        traffic_source=traffic_source,
                         avg_launch_us=dur * 1e6, launches_per_step=d["count"] / nprof,
                         algorithmic_bytes_per_launch=bytes_per_launch,
-                        flop_frac=d["flops"] / d["count"] / dur / FP32_PEAK, share_of_step=d["share"])
+                        flop_frac=d["flops"] / d["count"] / dur / peak_f, share_of_step=d["share"])
+
+    # BASELINE config 1 (C32-nb at batch 128, the reference's own notebook batch) on the GPU, next to the headline
+    if world == 1 and args.workload == "c32nb" and not args.no_secondary and not args.batch:
+        e2 = Engine(w["input_dims"], w["z_dims"], w["encoder"], w["decoder"], 0.0, 255.0, 0.01, 128, act_dtype=act).bind(local)
+        e2.set_params(init_params(e2.param_table, 42))
+        x2 = e2.to_device(np.random.default_rng(99).uniform(0, 255, (128, H, Wd, C)))
+        s2 = lambda i: e2.train_step(x2, lr, rf, kf, clip, seed=7000 + i)
+        for i in range(5):
+            s2(i)
+        dt2, per2 = timed_steps(e2, lambda i: s2(100 + i), 30, torch, dist, 1)
+        secondary["c32nb_b128"] = {"images_per_sec": 128 * 30 / dt2, "ms_per_step": 1e3 * dt2 / 30,
+                                   "ms_per_step_median_events": float(np.median(per2)),
+                                   "hbm_frac": algorithmic_bytes_per_step(w, 128, act) / (dt2 / 30) / HBM_PEAK}
+        e2.close()
 
     ms = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
-    step_bytes = algorithmic_bytes_per_step(w, B)
+    step_bytes = algorithmic_bytes_per_step(w, B, act)
+    med = float(np.median(per_step))
     out = {
-        "metric": "images/sec (train step, fwd+bwd+ELBO)", "value": value, "unit": "images/sec",
+        "metric": "images/sec (train step: fwd+bwd+ELBO+clipnorm-Adagrad)", "value": value, "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": act, "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d, %d scales, z=%s, enc/dec filters %s, batch %d per GPU (global %d), "
-                               "train step incl. Adagrad" % (args.workload, H, Wd, C, len(w["z_dims"]), w["z_dims"][0],
-                                                            w["encoder"]["filters"], B, B * world),
+                               "train step incl. Adagrad, %s activations" % (args.workload, H, Wd, C, len(w["z_dims"]), w["z_dims"][0],
+                                                            w["encoder"]["filters"], B, B * world, act),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "collective": "1 RCCL all-reduce of %d floats per step" % eng.R if world > 1 else "none"},
+                   "collective": "1 RCCL all-reduce of %d floats per step" % eng.R if collective else "none"},
         "finite": finite,
+        "timing": {"ms_per_step_median_events": med, "ms_per_step_min_events": float(per_step.min()),
+                   "ms_per_step_p90_events": float(np.percentile(per_step, 90)),
+                   "images_per_sec_median_events": B * world / (med * 1e-3),
+                   "note": "value / ms_per_step: wall clock over the K steps between barrier+synchronize, max over ranks "
+                           "(driver contract); *_events: HIP events on the engine's stream after every step (rank 0)"},
         "fwd_bwd_only": None if fb_ms is None else {"ms_per_step": fb_ms, "images_per_sec": B / (fb_ms * 1e-3)},
         "elbo_metrics": {k: float(v) for k, v in m.items()},
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "hbm_frac": step_bytes / (dt / args.steps) / HBM_PEAK,
-                          "fp32_flop_frac": 3 * w["F"] * B / (dt / args.steps) / FP32_PEAK},
+                          "hbm_frac_median_events": step_bytes / (med * 1e-3) / HBM_PEAK,
+                          "flop_frac": 3 * w["F"] * B / (dt / args.steps) / (BF16_PEAK if act == "bf16" else FP32_PEAK),
+                          "flop_peak": "bf16 MFMA 2.5 PF" if act == "bf16" else "fp32 157.3 TF"},
         "roofline": roofline,
+        "collective": coll,
+        "secondary": secondary or None,
     }
     if rank == 0:
         if kernels is not None:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "bench_kernels_%s_n%d.json" % (args.workload, world)), "w") as f:
+            with open(os.path.join(ROOT, "gpurun_out", "bench_kernels_%s_%s_n%d.json" % (args.workload, act, world)), "w") as f:
                 json.dump(kernels, f, indent=1, sort_keys=True)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 1
+#define MVAE_ABI_VERSION 2
 #define MVAE_MAX_LEVELS 16
 #define MVAE_MAX_BLOCKS 16
 #define MVAE_NAME_CAP 96
@@ -43,6 +43,10 @@ extern "C" {
 #define MVAE_E_STATE (-2)     /* call order: not bound, backward without training forward, ...  */
 #define MVAE_E_HIP (-3)       /* a HIP runtime call or kernel launch failed                      */
 #define MVAE_E_NOMEM (-4)     /* caller-provided workspace too small                             */
+
+#define MVAE_ACT_F32 0         /* activations, saved tensors and activation gradients in float32           */
+#define MVAE_ACT_BF16 1        /* ... stored as bfloat16 (wide [M,c] tensors only); parameters, gradients,  */
+                               /* optimiser state, BatchNorm statistics, latents and losses stay float32     */
 
 #define MVAE_REG_NONE 0
 #define MVAE_REG_L1 1         /* keras "l1": 0.01 * sum |w|   (layer_blocks.py:14)              */
@@ -65,6 +69,7 @@ typedef struct mvae_config {
   float min_value, max_value;                /* value range, multiscale_vae.py:65-66 */
   float sample_std;                          /* stddev of the sampling epsilon, :67 */
   int32_t max_batch;                         /* largest batch any later call will pass */
+  int32_t act_dtype;                         /* MVAE_ACT_F32 / MVAE_ACT_BF16 (BASELINE configs 4-5: bf16) */
 } mvae_config;
 
 typedef struct mvae_handle mvae_handle;
@@ -131,6 +136,12 @@ int mvae_train_step(mvae_handle* h, const mvae_step_io* io, float r_factor, floa
 int mvae_reg_loss(mvae_handle* h, float* out_dev, void* stream);
 /* decoder model (multiscale_vae.py:247-257): z [B,sum z] -> recon [B,H,W,C], inference mode. */
 int mvae_decode(mvae_handle* h, const float* z, int32_t batch, float* recon, void* stream);
+
+/* ---- input pipeline of train() (multiscale_vae.py:550-557: fit(x, x, batch_size, shuffle=True)): gather one batch
+ *      from an HBM-resident dataset.  dst[i, :] = src[idx[i], :]; src [N,row_elems], idx [n] int64 (device),
+ *      dst [n,row_elems]; stateless. ---- */
+int mvae_gather_rows(int32_t device, const float* src, const int64_t* idx, int64_t n, int64_t row_elems, float* dst,
+                     void* stream);
 
 /* ---- stand-alone Laplacian pyramid.  Replaces the Keras models built by
  *      mvae/layer_blocks.py:23-99 (laplacian_transform_split) and :107-185 (laplacian_transform_merge, trainable=False),

@@ -4,12 +4,13 @@ import os
 
 from ._build import LIB_PATH
 
-MVAE_ABI_VERSION = 1
+MVAE_ABI_VERSION = 2
 MVAE_MAX_LEVELS = 16
 MVAE_MAX_BLOCKS = 16
 MVAE_NAME_CAP = 96
 MVAE_OK, MVAE_E_INVALID, MVAE_E_STATE, MVAE_E_HIP, MVAE_E_NOMEM = 0, -1, -2, -3, -4
 REG_NAMES = {0: None, 1: "l1", 2: "l2"}
+ACT_DTYPES = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 
 _I32xL = C.c_int32 * MVAE_MAX_LEVELS
 _I32xB = C.c_int32 * MVAE_MAX_BLOCKS
@@ -27,6 +28,7 @@ class MvaeConfig(C.Structure):
         ("dec_kh", _I32xB), ("dec_kw", _I32xB), ("dec_sh", _I32xB), ("dec_sw", _I32xB),
         ("min_value", C.c_float), ("max_value", C.c_float), ("sample_std", C.c_float),
         ("max_batch", C.c_int32),
+        ("act_dtype", C.c_int32),
     ]
 
 
@@ -65,6 +67,7 @@ SYMBOLS = {
     "mvae_train_step": (C.c_int, [_H, C.POINTER(MvaeStepIO), C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mvae_reg_loss": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "mvae_decode": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mvae_gather_rows": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "mvae_laplacian_split": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_void_p), C.c_void_p,
                                        C.c_void_p]),
@@ -105,8 +108,11 @@ def load_library(path=None):
     return lib
 
 
-def make_config(input_dims, z_dims, encoder, decoder, min_value, max_value, sample_std, max_batch):
+def make_config(input_dims, z_dims, encoder, decoder, min_value, max_value, sample_std, max_batch, act_dtype="f32"):
     cfg = MvaeConfig()
+    if act_dtype not in ACT_DTYPES:
+        raise ValueError("act_dtype must be one of %s" % sorted(ACT_DTYPES))
+    cfg.act_dtype = ACT_DTYPES[act_dtype]
     cfg.abi_version = MVAE_ABI_VERSION
     cfg.input_h, cfg.input_w, cfg.input_c = [int(v) for v in input_dims]
     if len(z_dims) > MVAE_MAX_LEVELS:

@@ -26,6 +26,12 @@ struct PreOp {               // transform applied to the BIG-side operand when i
 // the seed is read from DEVICE memory so that a captured hipGraph stays valid from step to step
 void launch_set_u64(uint64_t* dst, uint64_t v, hipStream_t s);
 void launch_zero(float* p, int64_t n, hipStream_t s);
+// Hyper-parameters live in a small DEVICE block (like the seed), written by a one-thread kernel ahead of the graph
+// launch: one captured hipGraph then serves every learning rate / loss factor (a step-decay schedule used to
+// instantiate a new graph per distinct lr).
+enum { HP_RF_OVER_B = 0, HP_KF_OVER_B = 1, HP_LR = 2, HP_CLIP = 3, HP_GRAD_SCALE = 4, HP_COUNT = 8 };
+void launch_set_f3(float* dst, float a, float b, float c, int n, hipStream_t s);
+void launch_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t n, int64_t row_elems, hipStream_t s);
 void launch_rng_normal(float* out, int64_t n, float stddev, const uint64_t* seed, uint32_t stream_id, hipStream_t s);
 void launch_rng_keepmask(float* out, int64_t n, float p_drop, const uint64_t* seed, uint32_t stream_id, hipStream_t s);
 
@@ -142,7 +148,7 @@ void launch_sample_kl(const float* mu, const float* lv, const float* eps, int ep
                       float* kl_out, int kl_stride, int kl_col, int B, int Z, hipStream_t s);
 // dmu = dz + kf/B * mu ; dlv = dz * eps * exp(lv) + kf/B * 0.5 * (exp(lv) - 1)
 void launch_sample_kl_bwd(const float* dz, const float* mu, const float* lv, const float* eps, int eps_stride,
-                          int eps_off, float* dmu, float* dlv, float kf_over_b, int B, int Z, hipStream_t s);
+                          int eps_off, float* dmu, float* dlv, const float* hp, int B, int Z, hipStream_t s);
 void launch_copy_cols(const float* src, int src_stride, int src_off, float* dst, int dst_stride, int dst_off, int B,
                       int n, hipStream_t s);
 
@@ -158,7 +164,7 @@ void launch_loss_fwd(const float* y, const float* recon, float* losses, int loss
                      int B, int H, int W, int C, hipStream_t s);
 // du = clipmask(m) * (v1-v0)/2 * rf/B * (-sign(y-recon)/N - 0.5*(sgn_ch/(C*HW) + incrop*sgn_cc/(C*ncrop)))
 void launch_loss_bwd(const float* y, const float* recon, const float* merged, const float* sgn, float* du, int B,
-                     int H, int W, int C, float v0, float v1, float rf_over_b, hipStream_t s);
+                     int H, int W, int C, float v0, float v1, const float* hp, hipStream_t s);
 // metrics[0] += B ; metrics[1+j] += sum_b losses[b,j]
 void launch_metrics(const float* losses, int ncol, int B, float* metrics, hipStream_t s);
 
@@ -172,15 +178,15 @@ void launch_slot_sum(const ChunkDesc* chunks, int nchunks, float* g, const float
 // g = g*grad_scale + reg'(w) ; norms[chunk] = sum over the chunk of g^2 (plain store: the per-tensor norm is then summed
 // in a fixed order by the apply pass, so every data-parallel replica computes bit-identical clip factors)
 void launch_opt_prepare(const float* w, float* g, const ChunkDesc* chunks, int nchunks, float* norms,
-                        float grad_scale, hipStream_t s);
+                        const float* hp, hipStream_t s);
 // clip per tensor ; a += g^2 ; w -= lr * g / (sqrt(a) + 1e-7)
 void launch_opt_apply(float* w, const float* g, float* a, const ChunkDesc* chunks, int nchunks, const float* norms,
-                      float lr, float clip_norm, hipStream_t s);
+                      const float* hp, bool clip, hipStream_t s);
 // reg[0] += sum 0.01|w| or 0.01 w^2
 void launch_reg_loss(const float* w, const ChunkDesc* chunks, int nchunks, float* out, hipStream_t s);
 // moving = moving*mom + stat*stat_scale*(1-mom)*corr ; corr = n/(n-1), n = B*per_image when per_image > 0
 struct StateDesc { int64_t offset; int32_t len; float momentum; float per_image; int32_t pad; };
-void launch_state_update(float* state, const float* stats, const StateDesc* descs, int ndesc, float stat_scale,
+void launch_state_update(float* state, const float* stats, const StateDesc* descs, int ndesc, const float* hp,
                          int B, hipStream_t s);
 void set_gauss_constants(const float* g9);
 void launch_bn2d_mean(const float* sum, const float* mov_mean, float* mean, int64_t M, int C, int training,

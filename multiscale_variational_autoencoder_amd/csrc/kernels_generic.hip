@@ -106,6 +106,40 @@ void launch_zero(float* p, int64_t n, hipStream_t s) {
 }
 __global__ void k_set_u64(uint64_t* dst, uint64_t v) { *dst = v; }
 void launch_set_u64(uint64_t* dst, uint64_t v, hipStream_t s) { hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, s, dst, v); }
+__global__ void k_set_f3(float* dst, float a, float b, float c, int n) {
+  if (n > 0) dst[0] = a;
+  if (n > 1) dst[1] = b;
+  if (n > 2) dst[2] = c;
+}
+// dst[i, :] = src[idx[i], :]   rows of row4 16-byte items (the train() input pipeline: batches are gathered on the
+// device from an HBM-resident dataset by a device permutation, multiscale_vae.py:550-557 `shuffle=True`)
+__global__ void __launch_bounds__(256) k_gather_rows(const float4* __restrict__ src, const int64_t* __restrict__ idx,
+                                                     float4* __restrict__ dst, int64_t n, int64_t row4) {
+  const int64_t total = n * row4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / row4, c = i - r * row4;
+    dst[i] = src[idx[r] * row4 + c];
+  }
+}
+__global__ void __launch_bounds__(256) k_gather_rows1(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                      float* __restrict__ dst, int64_t n, int64_t row) {
+  const int64_t total = n * row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / row, c = i - r * row;
+    dst[i] = src[idx[r] * row + c];
+  }
+}
+void launch_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t n, int64_t row_elems, hipStream_t s) {
+  if (n <= 0 || row_elems <= 0) return;
+  if (row_elems % 4 == 0)
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n * row_elems / 4)), dim3(256), 0, s, (const float4*)src, idx,
+                       (float4*)dst, n, row_elems / 4);
+  else
+    hipLaunchKernelGGL(k_gather_rows1, dim3(grid_for(n * row_elems)), dim3(256), 0, s, src, idx, dst, n, row_elems);
+}
+void launch_set_f3(float* dst, float a, float b, float c, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_f3, dim3(1), dim3(1), 0, s, dst, a, b, c, n);
+}
 void launch_rng_keepmask(float* out, int64_t n, float p_drop, const uint64_t* seed, uint32_t sid, hipStream_t s) {
   ProfScope ps("rng", (double)(4.0*n), 0.0, s);
   if (n <= 0) return;
@@ -1058,8 +1092,10 @@ void launch_sample_kl(const float* mu, const float* lv, const float* eps, int ep
 }
 __global__ void k_sample_kl_bwd(const float* __restrict__ dz, const float* __restrict__ mu,
                                 const float* __restrict__ lv, const float* __restrict__ eps, int eps_stride,
-                                int eps_off, float* __restrict__ dmu, float* __restrict__ dlv, float kfb, int B, int Z) {
+                                int eps_off, float* __restrict__ dmu, float* __restrict__ dlv,
+                                const float* __restrict__ hp, int B, int Z) {
   int64_t n = (int64_t)B * Z;
+  const float kfb = hp[HP_KF_OVER_B];
   GRID_STRIDE(i, n) {
     int j = (int)(i % Z);
     int64_t b = i / Z;
@@ -1070,10 +1106,10 @@ __global__ void k_sample_kl_bwd(const float* __restrict__ dz, const float* __res
   }
 }
 void launch_sample_kl_bwd(const float* dz, const float* mu, const float* lv, const float* eps, int eps_stride,
-                          int eps_off, float* dmu, float* dlv, float kf_over_b, int B, int Z, hipStream_t s) {
+                          int eps_off, float* dmu, float* dlv, const float* hp, int B, int Z, hipStream_t s) {
   ProfScope ps("latent", (double)(24.0*B*Z), 0.0, s);
   hipLaunchKernelGGL(k_sample_kl_bwd, dim3(grid_for((int64_t)B * Z)), dim3(kBlock), 0, s, dz, mu, lv, eps, eps_stride,
-                     eps_off, dmu, dlv, kf_over_b, B, Z);
+                     eps_off, dmu, dlv, hp, B, Z);
 }
 __global__ void k_copy_cols(const float* src, int ss, int so, float* dst, int ds, int dof, int B, int n) {
   int64_t t = (int64_t)B * n;
@@ -1246,8 +1282,9 @@ void launch_loss_fwd(const float* y, const float* recon, float* losses, int loss
 }
 __global__ void k_loss_bwd(const float* __restrict__ y, const float* __restrict__ r, const float* __restrict__ merged,
                            const float* __restrict__ sgn, float* __restrict__ du, int B, int H, int W, int C, float v0,
-                           float v1, float rfb, int cy0, int cy1, int cx0, int cx1) {
+                           float v1, const float* __restrict__ hp, int cy0, int cy1, int cx0, int cx1) {
   int64_t n = (int64_t)B * H * W * C;
+  const float rfb = hp[HP_RF_OVER_B];
   const float hw = (float)H * W, ncrop = (float)(cy1 - cy0) * (cx1 - cx0);
   const float half_range = (v1 - v0) * 0.5f;
   GRID_STRIDE(i, n) {
@@ -1271,13 +1308,13 @@ __global__ void k_loss_bwd(const float* __restrict__ y, const float* __restrict_
   }
 }
 void launch_loss_bwd(const float* y, const float* recon, const float* merged, const float* sgn, float* du, int B,
-                     int H, int W, int C, float v0, float v1, float rf_over_b, hipStream_t s) {
+                     int H, int W, int C, float v0, float v1, const float* hp, hipStream_t s) {
   ProfScope ps("loss", (double)(16.0*B*H*W*C), 0.0, s);
   int cy0, cy1, cx0, cx1;
   crop_box(H, W, &cy0, &cy1, &cx0, &cx1);
   int64_t n = (int64_t)B * H * W * C;
   hipLaunchKernelGGL(k_loss_bwd, dim3(grid_for(n)), dim3(kBlock), 0, s, y, recon, merged, sgn, du, B, H, W, C, v0, v1,
-                     rf_over_b, cy0, cy1, cx0, cx1);
+                     hp, cy0, cy1, cx0, cx1);
 }
 __global__ void __launch_bounds__(256) k_metrics(const float* __restrict__ losses, int ncol, int B,
                                                  float* __restrict__ metrics) {
@@ -1301,8 +1338,9 @@ void launch_metrics(const float* losses, int ncol, int B, float* metrics, hipStr
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_opt_prepare(const float* __restrict__ w, float* __restrict__ g,
                                                      const ChunkDesc* __restrict__ chunks, float* __restrict__ norms,
-                                                     float grad_scale) {
+                                                     const float* __restrict__ hp) {
   __shared__ float sh[16];
+  const float grad_scale = hp[HP_GRAD_SCALE];
   ChunkDesc cd = chunks[blockIdx.x];
   float acc = 0.f;
   for (int i = threadIdx.x; i < cd.len; i += blockDim.x) {
@@ -1317,9 +1355,9 @@ __global__ void __launch_bounds__(256) k_opt_prepare(const float* __restrict__ w
   if (threadIdx.x == 0) norms[blockIdx.x] = t;        // per-chunk partial, summed in order by k_opt_apply
 }
 void launch_opt_prepare(const float* w, float* g, const ChunkDesc* chunks, int nchunks, float* norms,
-                        float grad_scale, hipStream_t s) {
+                        const float* hp, hipStream_t s) {
   ProfScope ps("optimizer", (double)(0.0), 0.0, s);
-  hipLaunchKernelGGL(k_opt_prepare, dim3(nchunks), dim3(256), 0, s, w, g, chunks, norms, grad_scale);
+  hipLaunchKernelGGL(k_opt_prepare, dim3(nchunks), dim3(256), 0, s, w, g, chunks, norms, hp);
 }
 // ||g||^2 of every tensor: the block of a tensor's FIRST chunk adds up the tensor's per-chunk partials in a fixed
 // order (thread t takes partials t, t + 256, ...; block_sum is a fixed tree) -> tnorm[first chunk].  No float atomics:
@@ -1338,10 +1376,11 @@ __global__ void __launch_bounds__(256) k_opt_tnorm(const ChunkDesc* __restrict__
 }
 __global__ void __launch_bounds__(256) k_opt_apply(float* __restrict__ w, const float* __restrict__ g,
                                                    float* __restrict__ a, const ChunkDesc* __restrict__ chunks,
-                                                   const float* __restrict__ tnorm, float lr, float clip_norm) {
+                                                   const float* __restrict__ tnorm, const float* __restrict__ hp, int clip) {
   ChunkDesc cd = chunks[blockIdx.x];
+  const float lr = hp[HP_LR], clip_norm = hp[HP_CLIP];
   float f = 1.0f;
-  if (clip_norm > 0.f) {
+  if (clip) {
     const float nrm = sqrtf(tnorm[cd.first]);
     f = clip_norm / fmaxf(nrm, clip_norm);       // tf.clip_by_norm
   }
@@ -1354,11 +1393,11 @@ __global__ void __launch_bounds__(256) k_opt_apply(float* __restrict__ w, const 
   }
 }
 void launch_opt_apply(float* w, const float* g, float* a, const ChunkDesc* chunks, int nchunks, const float* norms,
-                      float lr, float clip_norm, hipStream_t s) {
+                      const float* hp, bool clip, hipStream_t s) {
   ProfScope ps("optimizer", (double)(0.0), 0.0, s);
   float* tnorm = const_cast<float*>(norms) + nchunks;           // second half of the norms buffer (runtime: 2 x nchunks)
-  if (clip_norm > 0.f) hipLaunchKernelGGL(k_opt_tnorm, dim3(nchunks), dim3(256), 0, s, chunks, norms, tnorm);
-  hipLaunchKernelGGL(k_opt_apply, dim3(nchunks), dim3(256), 0, s, w, g, a, chunks, (const float*)tnorm, lr, clip_norm);
+  if (clip) hipLaunchKernelGGL(k_opt_tnorm, dim3(nchunks), dim3(256), 0, s, chunks, norms, tnorm);
+  hipLaunchKernelGGL(k_opt_apply, dim3(nchunks), dim3(256), 0, s, w, g, a, chunks, (const float*)tnorm, hp, clip ? 1 : 0);
 }
 __global__ void __launch_bounds__(256) k_reg_loss(const float* __restrict__ w, const ChunkDesc* __restrict__ chunks,
                                                   float* __restrict__ out) {
@@ -1378,8 +1417,9 @@ void launch_reg_loss(const float* w, const ChunkDesc* chunks, int nchunks, float
   hipLaunchKernelGGL(k_reg_loss, dim3(nchunks), dim3(256), 0, s, w, chunks, out);
 }
 __global__ void k_state_update(float* __restrict__ state, const float* __restrict__ stats,
-                               const StateDesc* __restrict__ descs, float stat_scale, int B) {
+                               const StateDesc* __restrict__ descs, const float* __restrict__ hp, int B) {
   StateDesc d = descs[blockIdx.x];
+  const float stat_scale = hp[HP_GRAD_SCALE];
   float corr = 1.0f;
   if (d.per_image > 0.f) {       // fused 4-D BatchNorm: moving variance takes the Bessel-corrected batch variance
     float n = d.per_image * (float)B;
@@ -1390,11 +1430,11 @@ __global__ void k_state_update(float* __restrict__ state, const float* __restric
     state[o] = state[o] * d.momentum + stats[o] * stat_scale * corr * (1.0f - d.momentum);
   }
 }
-void launch_state_update(float* state, const float* stats, const StateDesc* descs, int ndesc, float stat_scale,
+void launch_state_update(float* state, const float* stats, const StateDesc* descs, int ndesc, const float* hp,
                          int B, hipStream_t s) {
   ProfScope ps("optimizer", (double)(0.0), 0.0, s);
   if (ndesc <= 0) return;
-  hipLaunchKernelGGL(k_state_update, dim3(ndesc), dim3(64), 0, s, state, stats, descs, stat_scale, B);
+  hipLaunchKernelGGL(k_state_update, dim3(ndesc), dim3(64), 0, s, state, stats, descs, hp, B);
 }
 
 // Gradient-slot copies (kernels.h: GradSlots) are laid out like the gradient arena, but only tensors of at most one

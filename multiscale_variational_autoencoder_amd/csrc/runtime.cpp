@@ -111,13 +111,15 @@ struct mvae_handle {
   float *xin = nullptr, *eps_buf = nullptr, *noise_buf = nullptr, *keep_buf = nullptr, *recon = nullptr,
         *losses = nullptr, *sgn = nullptr, *reg_tmp = nullptr;
   uint64_t* d_seed = nullptr;
-  int64_t off_seed = 0;
+  float* d_hp = nullptr;                    // kernels.h HP_*: loss factors, lr, clip, grad_scale (device-resident)
+  int64_t off_seed = 0, off_hp = 0;
   // concurrency: scale 0 runs on the caller's stream, every other scale on its own side stream (fork/join with
   // events); each ABI call is captured into a hipGraph per argument signature and replayed.
   // wgrad_streams: opt-in (MVAE_WGRAD_STREAMS=1).  Correct in eager mode, but the ~450 extra event calls per step
   // make the host the bottleneck there, and capturing that many cross-stream edges crashes hipGraph (ROCm 7.2).
   bool merge_side = false;
   bool multi_stream = true, use_graphs = true, wgrad_streams = false;
+  bool lsb_mask = true;                     // the depthwise backward takes the ReLU mask from the LSB of dt2 (MVAE_LSB_MASK=0: reads t1)
   hipStream_t side[MVAE_MAX_LEVELS] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MVAE_MAX_LEVELS] = {};
   std::map<std::string, hipGraphExec_t> graphs;
@@ -379,6 +381,7 @@ int build_plan(mvae_handle* h) {
   h->off_sdescs = b.ws_alloc((int64_t)(h->sdescs.size() * sizeof(StateDesc) + 3) / 4);
   h->off_norms = b.ws_alloc(2 * (int64_t)h->chunks.size());      // one partial ||g||^2 per chunk, then one total per tensor
   h->off_seed = b.ws_alloc(kAlign);
+  h->off_hp = b.ws_alloc(kAlign);
   h->off_slots = b.ws_alloc((int64_t)kGradSlots * h->P);
   h->ws_floats = b.wcur;
   return MVAE_OK;
@@ -409,6 +412,7 @@ void rebase_all(mvae_handle* h) {
   }
   rb(h->xin);
   h->d_seed = reinterpret_cast<uint64_t*>(base + h->off_seed);
+  h->d_hp = base + h->off_hp;
   rb(h->eps_buf); rb(h->noise_buf); rb(h->keep_buf); rb(h->recon); rb(h->losses); rb(h->sgn); rb(h->reg_tmp);
   h->d_chunks = reinterpret_cast<ChunkDesc*>(base + h->off_chunks);
   h->d_sdescs = reinterpret_cast<StateDesc*>(base + h->off_sdescs);
@@ -569,11 +573,12 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   float* bufC = acquire(h, sc, s);
   bool fused_dw;
   {
-    ProfScope ps(dw_uses_img(true, dual2, B, m.H, m.W, c) ? "k_dw_bwd_img" : (dual2 ? "k_dw_bwd_ring<true>" : "k_dw_bwd_ring<false>"),
-                 (dual2 ? 12.0 : 16.0) * B * HW * c,
+    const bool lsb = dual2 && h->lsb_mask;
+    ProfScope ps(dw_uses_img(true, lsb, B, m.H, m.W, c) ? "k_dw_bwd_img" : (lsb ? "k_dw_bwd_ring<true>" : "k_dw_bwd_ring<false>"),
+                 (lsb ? 12.0 : 16.0) * B * HW * c,
                  40.0 * B * HW * c, s);            // 3 passes when t1 is not read (mask in the LSB of dt2)
-    fused_dw = launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC, G + m.wd, G + m.bd, h->gslots, dual2, B,
-                                   m.H, m.W, c, s);
+    fused_dw = launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC, G + m.wd, G + m.bd, h->gslots,
+                                   dual2 && h->lsb_mask, B, m.H, m.W, c, s);
   }
   if (!fused_dw) {
     launch_mn_dt1pre(bufB, m.t1, m.g, sc.dgap, B, HW, c, 1.0f / (float)HW, s);
@@ -677,7 +682,9 @@ void join_scales(mvae_handle* h, hipStream_t main) {
 
 // ---- hipGraph cache: capture the launch sequence of one ABI call once per argument signature, then replay ----
 int run_captured(mvae_handle* h, const std::string& key, hipStream_t s, const std::function<void(hipStream_t)>& body) {
-  const bool eligible = h->use_graphs && !profiler().on && s != nullptr;
+  // a fork from a stream that itself joined the capture by a fork (the weight-gradient side streams) makes
+  // hipStreamEndCapture segfault under ROCm 7.2: that mode never captures, whatever the environment says
+  const bool eligible = h->use_graphs && !h->wgrad_streams && !profiler().on && s != nullptr;
   if (!eligible) { body(s); return MVAE_OK; }
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
@@ -751,6 +758,8 @@ int mvae_create(const mvae_config* cfg, mvae_handle** out) {
       return fail(nullptr, MVAE_E_INVALID, "Filters should be > 0 (decoder entry %d)", i);
   if (!(cfg->max_value > cfg->min_value)) return fail(nullptr, MVAE_E_INVALID, "max_value must exceed min_value");
   if (cfg->max_batch <= 0) return fail(nullptr, MVAE_E_INVALID, "max_batch must be > 0");
+  if (cfg->act_dtype != MVAE_ACT_F32 && cfg->act_dtype != MVAE_ACT_BF16)
+    return fail(nullptr, MVAE_E_INVALID, "act_dtype must be MVAE_ACT_F32 or MVAE_ACT_BF16");
   mvae_handle* h = new mvae_handle();
   h->cfg = *cfg;
   int rc = build_plan(h);
@@ -840,6 +849,7 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   if (const char* v = getenv("MVAE_GRAPHS")) h->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("MVAE_STREAMS")) h->multi_stream = atoi(v) != 0;
   if (const char* v = getenv("MVAE_WGRAD_STREAMS")) h->wgrad_streams = atoi(v) != 0;
+  if (const char* v = getenv("MVAE_LSB_MASK")) h->lsb_mask = atoi(v) != 0;
   if (const char* v = getenv("MVAE_MERGE_SIDE")) h->merge_side = atoi(v) != 0;   // all scales > 0 on ONE side stream
   if (h->wgrad_streams) h->use_graphs = false;
   // scale 0 (on the caller's stream) is the long pole of every step: the other scales only fill the gaps it leaves,
@@ -978,6 +988,8 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
   hipStream_t s0 = static_cast<hipStream_t>(stream);
   const float* P = h->dp;
   float* G = h->dr;
+  // loss factors go through the device hyper-parameter block: the captured graph does not depend on their values
+  launch_set_f3(h->d_hp + HP_RF_OVER_B, r_factor / (float)B, kl_factor / (float)B, 0.f, 2, s0);
   auto body = [=](hipStream_t s) {
   PreOp none{nullptr, nullptr, nullptr};
   h->ev_next = 0;
@@ -985,7 +997,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
   if (h->gslots.n) launch_slot_zero(h->d_slot_chunks, (int)h->slot_chunks.size(), h->gslots.base, h->gslots.stride, h->gslots.n, s);
   // ---- loss -> clip/denormalise -> merge
   launch_loss_bwd(h->last_x, h->recon, h->scales[0].merged, h->sgn, h->scales[0].dy, B, c.input_h, c.input_w, C,
-                  c.min_value, c.max_value, r_factor / (float)B, s);
+                  c.min_value, c.max_value, h->d_hp, s);
   for (int i = 0; i + 1 < L; ++i)
     launch_upsample_bwd(h->scales[i].dy, h->scales[i + 1].dy, B, h->scales[i + 1].H, h->scales[i + 1].W, C, s);
   fork_scales(h, s);
@@ -1060,7 +1072,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     }
     if (!fused_dz) launch_gemm_nt(d, P + sc.dd_w, sc.dz, B, sc.z, (int)sc.K, nullptr, 0, s);
     launch_sample_kl_bwd(sc.dz, sc.mu, sc.lv, h->last_eps, (int)h->Z, sc.z_off, sc.dmu, sc.dlv,
-                         kl_factor / (float)B, B, sc.z, s);
+                         h->d_hp, B, sc.z, s);
     const float* flat = sc.enc.back().mn.out;
     {   // dmu / dlv are per-scale buffers written once per backward: safe to read from the side stream
       hipStream_t w = wgrad_begin(h, sc, s);
@@ -1129,7 +1141,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
   };
   int rc = MVAE_OK;
   if (h->last_x == h->xin && h->last_eps == h->eps_buf)
-    rc = run_captured(h, fkey("B:%d:%a:%a", B, (double)r_factor, (double)kl_factor), s0, body);
+    rc = run_captured(h, fkey("B:%d", B), s0, body);
   else body(s0);
   if (rc != MVAE_OK) return rc;
   return check_launch(h, "mvae_backward");
@@ -1140,13 +1152,15 @@ int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_sca
   if (!h->bound) return fail(h, MVAE_E_STATE, "mvae_bind has not been called");
   hipStream_t s0 = static_cast<hipStream_t>(stream);
   const int Bt = h->last_train_B;
+  const bool clip = clip_norm > 0.f;
+  launch_set_f3(h->d_hp + HP_LR, lr, clip_norm, grad_scale, 3, s0);     // HP_LR, HP_CLIP, HP_GRAD_SCALE are adjacent
   auto body = [=](hipStream_t s) {
-    launch_opt_prepare(h->dp, h->dr, h->d_chunks, (int)h->chunks.size(), h->d_norms, grad_scale, s);
-    launch_opt_apply(h->dp, h->dr, h->da, h->d_chunks, (int)h->chunks.size(), h->d_norms, lr, clip_norm, s);
+    launch_opt_prepare(h->dp, h->dr, h->d_chunks, (int)h->chunks.size(), h->d_norms, h->d_hp, s);
+    launch_opt_apply(h->dp, h->dr, h->da, h->d_chunks, (int)h->chunks.size(), h->d_norms, h->d_hp, clip, s);
     // BN moving statistics from the (all-reduced, hence grad_scale) batch statistics
-    launch_state_update(h->ds, h->dr + h->P, h->d_sdescs, (int)h->sdescs.size(), grad_scale, Bt, s);
+    launch_state_update(h->ds, h->dr + h->P, h->d_sdescs, (int)h->sdescs.size(), h->d_hp, Bt, s);
   };
-  int rc = run_captured(h, fkey("A:%d:%a:%a:%a", Bt, (double)lr, (double)clip_norm, (double)grad_scale), s0, body);
+  int rc = run_captured(h, fkey("A:%d:%d", Bt, clip ? 1 : 0), s0, body);
   if (rc != MVAE_OK) return rc;
   return check_launch(h, "mvae_apply_adagrad");
 }
@@ -1183,6 +1197,14 @@ int mvae_decode(mvae_handle* h, const float* z, int32_t batch, float* recon, voi
   merge_forward(h, batch, recon, s);
   h->last_B = 0;   // activations no longer belong to a training forward
   return check_launch(h, "mvae_decode");
+}
+
+int mvae_gather_rows(int32_t device, const float* src, const int64_t* idx, int64_t n, int64_t row_elems, float* dst,
+                     void* stream) {
+  if (!src || !idx || !dst || n < 0 || row_elems <= 0) return MVAE_E_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  launch_gather_rows(src, idx, dst, n, row_elems, static_cast<hipStream_t>(stream));
+  return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
 }
 
 // ---- stand-alone Laplacian pyramid (layer_blocks.py:23-185), stateless ----------------------

@@ -5,6 +5,7 @@ the path is in libmvae_hip.so.  Replaces what Keras/TensorFlow did for the refer
 mvae/multiscale_vae.py:550-557 called `self._model_trainable.fit`.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -21,9 +22,12 @@ def _ptr(t):
 
 
 class Engine:
-    def __init__(self, input_dims, z_dims, encoder, decoder, min_value, max_value, sample_std, max_batch):
+    def __init__(self, input_dims, z_dims, encoder, decoder, min_value, max_value, sample_std, max_batch,
+                 act_dtype="f32"):
         self.lib = _abi.load_library()
-        self.cfg = _abi.make_config(input_dims, z_dims, encoder, decoder, min_value, max_value, sample_std, max_batch)
+        self.act_dtype = act_dtype
+        self.cfg = _abi.make_config(input_dims, z_dims, encoder, decoder, min_value, max_value, sample_std, max_batch,
+                                    act_dtype)
         self.input_dims = tuple(int(v) for v in input_dims)
         self.levels = len(z_dims)
         self.max_batch = int(max_batch)
@@ -103,6 +107,8 @@ class Engine:
         # all kernels run on this stream: a real (non-default) HIP stream, so that the library can capture its
         # launch sequences into hipGraphs; torch ops that touch our buffers are issued under it as well
         self.stream = torch.cuda.Stream(self.device)
+        self.copy_stream = None                 # pinned double-buffered H2D of datasets that do not fit in HBM
+        self.dataset = None
         self.bound = True
         return self
 
@@ -189,6 +195,12 @@ class Engine:
             out["losses"] = torch.empty((B, 3 + self.levels), **f32); io.losses = out["losses"].data_ptr()
         self._keep = (x, eps, noise, keep_mask)       # backward reads x / eps again
         self._enter()
+        # The kernels run on self.stream, not on the stream the caller allocated these tensors on: tell torch's caching
+        # allocator, or a tensor dropped by the caller (train() feeds a fresh batch every step and the host runs several
+        # steps ahead of the device) is handed out again while this step's kernels still read it.
+        for t in self._keep:
+            if t is not None:
+                t.record_stream(self.stream)
         self._check(self.lib.mvae_forward(self.h, C.byref(io), self._stream()))
         if out:
             self.sync()                               # the caller reads the outputs from another stream
@@ -201,17 +213,128 @@ class Engine:
         self._check(self.lib.mvae_apply_adagrad(self.h, float(lr), float(clip_norm if clip_norm else 0.0),
                                                 float(grad_scale), self._stream()))
 
-    def train_step(self, x, lr, r_factor, kl_factor, clip_norm, eps=None, noise=None, keep_mask=None, seed=0):
-        """forward + backward (+ one RCCL all-reduce of the reduce arena when torch.distributed is up) + Adagrad."""
+    def collective_active(self, force=False):
+        """True when train_step all-reduces: torch.distributed is up and (world > 1 or forced).  `force` (or
+        MVAE_FORCE_COLLECTIVE=1) sends a world-size-1 group through the same RCCL call, which is how the
+        collective branch is exercised on a one-GPU box."""
+        dist = self.torch.distributed
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size() > 1 or force or os.environ.get("MVAE_FORCE_COLLECTIVE", "") == "1"
+
+    def train_step(self, x, lr, r_factor, kl_factor, clip_norm, eps=None, noise=None, keep_mask=None, seed=0,
+                   force_collective=False, timing=None):
+        """forward + backward (+ one RCCL all-reduce of the reduce arena when torch.distributed is up) + Adagrad.
+        timing: optional list; a (start, end) pair of torch events around the all-reduce is appended."""
         self.forward(x, True, eps, noise, keep_mask, seed, outputs=())
         self.backward(r_factor, kl_factor)
         scale = 1.0
-        dist = self.torch.distributed
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self.collective_active(force_collective):
+            dist = self.torch.distributed
             with self.torch.cuda.stream(self.stream):
+                if timing is not None:
+                    e0 = self.torch.cuda.Event(enable_timing=True); e1 = self.torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
                 dist.all_reduce(self.reduce)              # grads | BN batch statistics | metrics, one message
+                if timing is not None:
+                    e1.record(self.stream)
+                    timing.append((e0, e1))
             scale = 1.0 / dist.get_world_size()
         self.apply(lr, clip_norm, scale)
+
+    def train_step_abi(self, x, lr, r_factor, kl_factor, clip_norm, eps=None, noise=None, keep_mask=None, seed=0):
+        """The single-device step through ONE C-ABI call, mvae_train_step (what INTEGRATION.md binds)."""
+        io = _abi.MvaeStepIO()
+        io.x, io.batch, io.training, io.seed = x.data_ptr(), int(x.shape[0]), 1, int(seed) & (2 ** 64 - 1)
+        io.eps = eps.data_ptr() if eps is not None else None
+        io.noise = noise.data_ptr() if noise is not None else None
+        io.keep_mask = keep_mask.data_ptr() if keep_mask is not None else None
+        self._keep = (x, eps, noise, keep_mask)
+        self._enter()
+        for t in self._keep:
+            if t is not None:
+                t.record_stream(self.stream)
+        self._check(self.lib.mvae_train_step(self.h, C.byref(io), float(r_factor), float(kl_factor), float(lr),
+                                             float(clip_norm if clip_norm else 0.0), self._stream()))
+
+    # ------------------------------------------------------------------ train() input pipeline
+    def load_dataset(self, x, resident_fraction=0.5):
+        """Make x [N,H,W,C] float32 the source of gather_batch().  If it fits in `resident_fraction` of the free HBM
+        it is uploaded once and batches are gathered on the device by a HIP kernel from a device permutation; otherwise
+        it stays on the host and batches travel through two pinned buffers with asynchronous H2D copies on a copy stream
+        (the gather then runs on the host into the pinned buffer)."""
+        torch = self.torch
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if tuple(x.shape[1:]) != self.input_dims:
+            raise ValueError("dataset must be [N,%d,%d,%d]" % self.input_dims)
+        free, _ = torch.cuda.mem_get_info(self.device)
+        self.sync()
+        ds = dict(n=len(x), row=int(np.prod(x.shape[1:])), resident=x.nbytes <= resident_fraction * free, perm=None)
+        if ds["resident"]:
+            with torch.cuda.stream(self.stream):
+                ds["data"] = torch.empty(x.shape, dtype=torch.float32, device=self.device)
+                step = max(1, (256 << 20) // max(x[0].nbytes, 1))
+                for i in range(0, len(x), step):
+                    ds["data"][i:i + step].copy_(torch.from_numpy(x[i:i + step]), non_blocking=False)
+                ds["buf"] = [torch.empty((self.max_batch,) + self.input_dims, dtype=torch.float32, device=self.device)
+                             for _ in range(2)]
+        else:
+            ds["host"] = x
+            ds["pin"] = [torch.empty((self.max_batch,) + self.input_dims, dtype=torch.float32).pin_memory()
+                         for _ in range(2)]
+            ds["buf"] = [torch.empty((self.max_batch,) + self.input_dims, dtype=torch.float32, device=self.device)
+                         for _ in range(2)]
+            ds["copied"] = [None, None]            # H2D done (recorded on the copy stream)
+            ds["consumed"] = [None, None]          # the step that read buf[k] is enqueued (recorded on self.stream)
+            if self.copy_stream is None:
+                self.copy_stream = torch.cuda.Stream(self.device)
+        ds["tick"] = 0
+        self.dataset = ds
+        return ds
+
+    def set_permutation(self, order):
+        """Upload the epoch's sample order (int64 indices into the dataset)."""
+        ds, torch = self.dataset, self.torch
+        order = np.ascontiguousarray(order, dtype=np.int64)
+        if ds["resident"]:
+            with torch.cuda.stream(self.stream):
+                ds["perm"] = torch.from_numpy(order).to(self.device)
+        else:
+            ds["perm"] = order
+
+    def gather_batch(self, start, count):
+        """Device tensor [count,H,W,C] = dataset[perm[start:start+count]], ready on self.stream."""
+        ds, torch = self.dataset, self.torch
+        k = ds["tick"] & 1
+        ds["tick"] += 1
+        out = ds["buf"][k][:count]
+        if ds["resident"]:
+            idx = ds["perm"][start:start + count]
+            self._check_rc(self.lib.mvae_gather_rows(self.device.index, _ptr(ds["data"]), _ptr(idx), count, ds["row"],
+                                                     _ptr(out), self._stream()))
+            return out
+        if ds["copied"][k] is not None:
+            ds["copied"][k].synchronize()          # the pinned buffer is free again
+        pin = ds["pin"][k][:count]
+        np.take(ds["host"], ds["perm"][start:start + count], axis=0, out=pin.numpy())
+        if ds["consumed"][k] is not None:
+            self.copy_stream.wait_event(ds["consumed"][k])
+        with torch.cuda.stream(self.copy_stream):
+            out.copy_(pin, non_blocking=True)
+            ds["copied"][k] = torch.cuda.Event(); ds["copied"][k].record(self.copy_stream)
+        self.stream.wait_event(ds["copied"][k])
+        return out
+
+    def batch_consumed(self):
+        """Call after the step that read the last gather_batch() result has been enqueued."""
+        ds = self.dataset
+        if ds is not None and not ds["resident"]:
+            k = (ds["tick"] - 1) & 1
+            ds["consumed"][k] = self.torch.cuda.Event(); ds["consumed"][k].record(self.stream)
+
+    def _check_rc(self, rc):
+        if rc != _abi.MVAE_OK:
+            raise MvaeError("mvae error %d" % rc)
 
     def metrics(self):
         """{count, vae_r_loss, r_exp, vae_kl_loss, kl_scale_i} means of the last forward (synchronises)."""
@@ -240,12 +363,15 @@ class Engine:
         self.sync()
         return out
 
-    def tensor(self, name, batch):
-        """Debug/parity view of a saved intermediate of the last forward: [batch, elems_per_image]."""
+    def tensor_nosync(self, name, batch):
         p, n = C.c_void_p(), C.c_int64()
         rc = self.lib.mvae_tensor_lookup(self.h, name.encode(), C.byref(p), C.byref(n))
         if rc != _abi.MVAE_OK:
             raise KeyError(name)
         off = (p.value - self.workspace.data_ptr()) // 4
-        self.sync()
         return self.workspace[off:off + batch * n.value].view(batch, n.value)
+
+    def tensor(self, name, batch):
+        """Debug/parity view of a saved intermediate of the last forward: [batch, elems_per_image]."""
+        self.sync()
+        return self.tensor_nosync(name, batch)

@@ -133,7 +133,7 @@ def laplacian_transform_split(input_dims, levels, name=None, min_value=0.0, max_
 
 def laplacian_transform_merge(input_dims, levels, name=None, min_value=0.0, max_value=255.0, trainable=False,
                               filters=32, activation="relu", kernel_regularizer="l1",
-                              kernel_initializer="glorot_uniform"):
+                              kernel_initializer="glorot_normal"):
     """layer_blocks.py:107-185 with trainable=False: upsample-and-add from the coarsest level, denormalise, clip."""
     if trainable:
         raise NotImplementedError("laplacian_transform_merge(trainable=True) is not built (see the module docstring)")

@@ -36,6 +36,24 @@ def _norm_block_dict(d, what):
             "strides": [(int(a[0]), int(a[1])) for a in s]}
 
 
+def shard_batches(order, batch_size, world=1, rank=0):
+    """The rank's share of every global batch of one epoch.  `order` is the epoch's sample order; global batch b is
+    order[b*batch_size:(b+1)*batch_size] (last partial batch kept, like keras); rank r takes positions
+    r*per .. (r+1)*per - 1 of it, per = ceil(len/world), positions past the end wrapping around to the batch's first
+    samples -- nothing is dropped, and every rank takes the same number of steps with the same local batch size.
+    Returns (local, spans): the rank's indices concatenated, and (offset, count) of each batch inside `local`."""
+    order = np.asarray(order, dtype=np.int64)
+    local, spans, off = [], [], 0
+    for start in range(0, len(order), batch_size):
+        idx = order[start:start + batch_size]
+        per = -(-len(idx) // world)
+        take = idx[(rank * per + np.arange(per)) % len(idx)] if world > 1 else idx
+        spans.append((off, len(take)))
+        off += len(take)
+        local.append(take)
+    return (np.concatenate(local) if local else np.zeros(0, np.int64)), spans
+
+
 class History:
     def __init__(self):
         self.history = OrderedDict()
@@ -129,7 +147,7 @@ class MultiscaleVAE:
             max_value=255.0,
             sample_std=0.01,
             channels_index=2,
-            *, seed=42, max_batch=None, device=None):
+            *, seed=42, max_batch=None, device=None, act_dtype="f32"):
         # --- argument checking (multiscale_vae.py:34-38)
         if encoder is None:
             raise ValueError("encoder cannot be None")
@@ -161,6 +179,7 @@ class MultiscaleVAE:
         self._seed = int(seed)
         self._step = 0
         self._device = device
+        self._act_dtype = act_dtype            # "f32" | "bf16" activation storage (BASELINE configs 4-5 use bf16)
         self._engine = None
         logger.info("Building multiscale VAE plan")
         self._engine = self._make_engine(int(max_batch) if max_batch else 1)     # host-only: validates + tables
@@ -174,7 +193,7 @@ class MultiscaleVAE:
     # ==========================================================================
     def _make_engine(self, max_batch):
         return Engine(self._inputs_dims, self._z_latent_dims, self._encoder_config, self._decoder_config,
-                      self._min_value, self._max_value, self._sample_std, max_batch)
+                      self._min_value, self._max_value, self._sample_std, max_batch, act_dtype=self._act_dtype)
 
     def _sync_host(self):
         """Pull weights / optimiser state back from a bound engine."""
@@ -201,8 +220,11 @@ class MultiscaleVAE:
         return eng
 
     def _next_seed(self):
+        """Device-RNG seed of the next call: a function of (seed, step, rank) -- data-parallel replicas draw independent
+        epsilon / GaussianNoise / SpatialDropout for their shards (weight initialisation stays rank-independent)."""
         self._step += 1
-        return (self._seed * 0x9E3779B97F4A7C15 + self._step) & (2 ** 63 - 1)
+        rank = int(getattr(self, "_rank", 0))
+        return ((self._seed * 0x9E3779B97F4A7C15 + self._step) ^ (rank * 0xD1B54A32D192ED03)) & (2 ** 63 - 1)
 
     def get_config(self):
         return dict(input_dims=list(self._inputs_dims), z_dims=list(self._z_latent_dims),
@@ -245,6 +267,11 @@ class MultiscaleVAE:
         return eng
 
     def _fit(self, x, batch_size, shuffle, epochs, initial_epoch, callbacks, verbose):
+        """keras.Model.fit as the reference calls it (multiscale_vae.py:550-557).  The dataset is made device
+        resident once (Engine.load_dataset) and every batch is gathered on the device from the epoch's permutation, so
+        the host only enqueues work; under data parallelism rank r takes every world-th share of each global batch, the
+        tail of a batch that does not divide wraps around to the batch's first samples (nothing is dropped, a few
+        samples of that batch count twice) so that every rank enqueues the same number of all-reduces."""
         if self._compiled is None:
             raise RuntimeError("compile() must be called before fit()")
         import torch
@@ -252,31 +279,41 @@ class MultiscaleVAE:
         world, rank = 1, 0
         if dist.is_available() and dist.is_initialized():
             world, rank = dist.get_world_size(), dist.get_rank()
+        self._rank = rank
         n = len(x)
         hist = History()
         c = self._compiled
         for cb in callbacks:
             if hasattr(cb, "set_vae"):
                 cb.set_vae(self)
+        if n == 0:
+            return hist
+        per_max = -(-min(batch_size, n) // world)
+        eng = self._ensure_engine(per_max)
+        eng.load_dataset(x)
         for epoch in range(initial_epoch, epochs):
             for cb in callbacks:
                 if hasattr(cb, "on_epoch_begin"):
                     cb.on_epoch_begin(epoch, {})
             # the shuffle of epoch e depends on (seed, e) only: a run resumed with initial_epoch=e sees the same batches
             order = np.random.default_rng([self._seed + 1, epoch]).permutation(n) if shuffle else np.arange(n)
+            local, spans = shard_batches(order, batch_size, world, rank)
             t0 = time.time()
-            acc, seen, eng = None, 0, None
-            for bi, start in enumerate(range(0, n, batch_size)):
-                idx = order[start:start + batch_size]          # last partial batch kept, like keras
-                if world > 1:
-                    per = len(idx) // world
-                    if per == 0:
-                        continue
-                    idx = idx[rank * per:(rank + 1) * per]
-                eng = self.train_on_batch(x[idx])
+            acc, seen, fed = None, 0, None
+            for bi, (off, cnt) in enumerate(spans):
+                eng = self._ensure_engine(per_max)
+                if fed is not eng:                              # first batch, or a callback re-bound the engine
+                    if eng.dataset is None:
+                        eng.load_dataset(x)
+                    eng.set_permutation(local)
+                    fed = eng
+                xb = eng.gather_batch(off, cnt)
+                eng.train_step(xb, self._learning_rate, c["r_loss_factor"], c["kl_loss_factor"], c["clip_norm"],
+                               seed=self._next_seed())
+                eng.batch_consumed()
                 with torch.cuda.stream(eng.stream):            # stays on the device: no per-step sync
                     m = eng.reduce[eng.metrics_off:eng.metrics_off + 4 + self._levels]
-                    acc = m.clone() if acc is None else acc + m
+                    acc = m.clone() if acc is None else acc.add_(m)
                 seen += 1
                 for cb in callbacks:
                     if hasattr(cb, "on_batch_end"):
@@ -284,12 +321,14 @@ class MultiscaleVAE:
             logs = {}
             if acc is not None:
                 eng.sync()
+                dt = max(time.time() - t0, 1e-9)
                 a = acc.cpu().numpy().astype(np.float64)
                 cnt = max(a[0], 1.0)
                 logs = {"vae_r_loss": a[1] / cnt, "vae_kl_loss": a[3] / cnt}
                 reg = eng.reg_loss()
                 logs["loss"] = c["r_loss_factor"] * a[2] / cnt + c["kl_loss_factor"] * a[3] / cnt + reg
-                logs["images_per_sec"] = a[0] / max(time.time() - t0, 1e-9)
+                logs["images_per_sec"] = a[0] / dt
+                logs["samples"] = a[0]
             hist.epoch.append(epoch)
             for k, v in logs.items():
                 hist.history.setdefault(k, []).append(float(v))

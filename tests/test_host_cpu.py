@@ -140,3 +140,24 @@ def test_collage_resize_and_png_writer(tmp_path):
         assert np.array_equal(np.asarray(Image.open(path)), np.rint(img * 255).astype(np.uint8))
     except ImportError:
         pass
+
+
+def test_shard_batches_drops_nothing_and_keeps_ranks_in_step():
+    """Data-parallel feed: every sample of every global batch is taken by some rank, all ranks take the same
+    number of steps with the same local batch sizes, the tail wraps instead of being dropped."""
+    from multiscale_variational_autoencoder_amd.multiscale_vae import shard_batches
+    n, bs = 103, 16                      # 6 full batches + a tail of 7
+    order = np.random.default_rng(0).permutation(n)
+    for world in (1, 2, 3, 8):
+        shards = [shard_batches(order, bs, world, r) for r in range(world)]
+        spans = [s[1] for s in shards]
+        assert all(sp == spans[0] for sp in spans)                       # same steps, same local batch sizes
+        assert len(spans[0]) == -(-n // bs)
+        for b, (off, cnt) in enumerate(spans[0]):
+            g = order[b * bs:(b + 1) * bs]
+            taken = np.concatenate([sh[0][off:off + cnt] for sh in shards])
+            assert set(taken.tolist()) == set(g.tolist())                # nothing dropped
+            assert len(taken) == world * (-(-len(g) // world))            # padded by wrap-around only
+            assert len(taken) - len(g) < world
+    local, spans = shard_batches(order, bs, 1, 0)
+    assert np.array_equal(local, order) and sum(c for _, c in spans) == n

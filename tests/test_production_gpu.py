@@ -1,0 +1,226 @@
+"""GPU: the PRODUCTION path -- replayed hipGraphs, one HIP stream per scale, on-device Philox draws, the single
+mvae_train_step ABI call, the RCCL collective branch, and train()'s device-resident input pipeline -- held to the same
+oracle bounds as the eager / injected path of test_parity_gpu.py.  The Philox draws (epsilon, GaussianNoise,
+SpatialDropout mask) are read back through mvae_tensor_lookup and handed to the oracle, so the oracle evaluates the
+very same sample the graph replay computed."""
+import os
+import socket
+import time
+
+import numpy as np
+import pytest
+
+from tests.common import (COMPILE, CONFIGS, engine_args, grad_errors, make_inputs, oracle_config, rel_err,
+                          structurally_zero)
+from tests.test_parity_gpu import TOL_ELBO, TOL_GRAD, TOL_RECON_ABS
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(name, B, **kw):
+    from multiscale_variational_autoencoder_amd.engine import Engine
+    args = engine_args(name, B)
+    args.update(kw)
+    return Engine(**args).bind()
+
+
+@pytest.mark.parametrize("name,B", [("c32nb", 8), ("c32nb", 16)])
+def test_graph_replay_with_device_rng_under_the_oracle(name, B):
+    """forward + backward + Adagrad through captured graphs with nothing injected; step 0 captures, step 1 replays and
+    is the one compared."""
+    from oracle.mvae_oracle import Oracle
+    io = make_inputs(name, B)
+    eng = _engine(name, B)
+    eng.set_params(io["params"]); eng.set_state(io["state"])
+    x = eng.to_device(io["x"])
+    # step 0: capture (lr = 0 keeps the weights, accumulators still move -> reset below)
+    eng.forward(x, True, seed=11, outputs=()); eng.backward(COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    eng.sync()
+    # step 1: replay with another seed
+    eng.forward(x, True, seed=12, outputs=()); eng.backward(COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    eng.sync()
+    H, W, C = CONFIGS[name]["input_dims"]
+    eps = eng.tensor("eps", B).cpu().numpy().reshape(B, -1)
+    noise = eng.tensor("noise", B).cpu().numpy().reshape(B, H, W, C)
+    keep = eng.tensor("keep_mask", B).cpu().numpy().reshape(B, C)
+    recon = eng.tensor("recon", B).cpu().numpy().reshape(B, H, W, C)
+    losses = eng.tensor("losses", B).cpu().numpy().astype(np.float64)
+    assert set(np.unique(keep)) <= {0.0, 1.0}
+    res, G = Oracle(oracle_config(name)).loss_and_grads(io["params"], io["state"], io["x"], eps, noise, keep,
+                                                        COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    elbo = (COMPILE["r_loss_factor"] * losses[:, 1] + COMPILE["kl_loss_factor"] * losses[:, 2]).mean()
+    assert abs(elbo - res["data_loss"]) / abs(res["data_loss"]) <= TOL_ELBO
+    assert rel_err(losses[:, 0], res["r"]) <= TOL_ELBO and rel_err(losses[:, 3:], res["kl_scale"]) <= TOL_ELBO
+    assert np.abs(recon - res["recon"]).max() <= TOL_RECON_ABS
+    m = eng.metrics()
+    assert abs(m["vae_r_loss"] - res["r"].mean()) <= TOL_ELBO * abs(res["r"].mean())
+    assert abs(m["vae_kl_loss"] - res["kl"].mean()) <= TOL_ELBO * abs(res["kl"].mean())
+    from tests.common import reg_grad
+    g = eng.get_grads()
+    rg = reg_grad(io["params"], eng.param_table)
+    gerr = grad_errors({k: g[k].astype(np.float64) + rg[k] for k in G}, G)
+    worst = max(gerr.items(), key=lambda kv: kv[1])
+    assert worst[1] <= TOL_GRAD, worst
+
+
+def test_mvae_train_step_abi_equals_the_three_calls():
+    """mvae_train_step (the entry INTEGRATION.md binds) == mvae_forward + mvae_backward + mvae_apply_adagrad on the same
+    injected inputs: losses identical bit for bit (deterministic kernels), parameters within float-atomic noise, and
+    both within the oracle bound of test_adagrad_trajectory_parity."""
+    from oracle.mvae_oracle import Oracle
+    name, B = "c32nb", 4
+    io = make_inputs(name, B)
+    runs = []
+    for abi in (False, True):
+        eng = _engine(name, B)
+        eng.set_params(io["params"]); eng.set_state(io["state"])
+        d = {k: eng.to_device(io[k]) for k in ("x", "eps", "noise", "keep")}
+        fn = eng.train_step_abi if abi else eng.train_step
+        fn(d["x"], COMPILE["learning_rate"], COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"], COMPILE["clip_norm"],
+           eps=d["eps"], noise=d["noise"], keep_mask=d["keep"])
+        eng.sync()
+        runs.append((eng.tensor("losses", B).cpu().numpy().copy(), eng.get_params(), eng.get_state()))
+    (la, pa, sa), (lb, pb, sb) = runs
+    assert np.array_equal(la, lb)
+    orc = Oracle(oracle_config(name))
+    p0 = {k: np.asarray(v, np.float64) for k, v in io["params"].items()}
+    a0 = {k: np.full(v.shape, 0.1) for k, v in p0.items()}
+    st0 = {k: np.asarray(v, np.float64) for k, v in io["state"].items()}
+    res, G, p1, a1, st1 = orc.train_step(p0, a0, st0, io["x"], io["eps"], io["noise"], io["keep"],
+                                         COMPILE["learning_rate"], COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"],
+                                         COMPILE["clip_norm"])
+    zero = structurally_zero(G)
+    lr = COMPILE["learning_rate"]
+    for k in p1:
+        w = 0.1 if k in zero else 1.0
+        assert w * np.abs(pb[k] - p1[k]).max() / lr <= 3e-2, k
+        assert w * np.abs(pb[k] - pa[k]).max() / lr <= 3e-2, k
+    for k in st1:
+        assert rel_err(sb[k], np.asarray(st1[k])) <= 1e-5, k
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rccl_worker(rank, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # "nccl" IS RCCL on ROCm
+    name, B = "c32nb", 8
+    io = make_inputs(name, B)
+    out = {}
+    for tag, force in (("plain", False), ("rccl", True)):
+        eng = _engine(name, B)
+        eng.set_params(io["params"]); eng.set_state(io["state"])
+        d = {k: eng.to_device(io[k]) for k in ("x", "eps", "noise", "keep")}
+        timing = []
+        for step in range(3):          # graph capture on step 0, replays after; the all-reduce sits between two graphs
+            eng.train_step(d["x"], COMPILE["learning_rate"], COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"],
+                           COMPILE["clip_norm"], eps=d["eps"], noise=d["noise"], keep_mask=d["keep"],
+                           force_collective=force, timing=timing)
+        eng.sync()
+        assert eng.collective_active(force) == force
+        assert len(timing) == (3 if force else 0)
+        if force:
+            out["allreduce_ms"] = np.array([a.elapsed_time(b) for a, b in timing])
+        out[tag + "_losses"] = eng.tensor("losses", B).cpu().numpy().copy()
+        for k, v in eng.get_params().items():
+            out[tag + "/" + k] = v
+        m = eng.metrics()
+        out[tag + "_count"] = np.float64(m["count"])
+    np.savez(os.path.join(out_dir, "rccl.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_rccl_allreduce_branch_world1(tmp_path):
+    """RCCL executes: a one-rank `nccl` group, Engine.train_step forced through its all-reduce branch (the reduce arena
+    on the engine's non-default stream, between the backward and the apply graph launches) equals the step without the
+    collective (sum over one rank = identity, grad_scale = 1)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    f = np.load(tmp_path / "rccl.npz")
+    assert np.array_equal(f["plain_losses"], f["rccl_losses"])
+    assert float(f["plain_count"]) == float(f["rccl_count"]) == 8.0
+    keys = [k[6:] for k in f.files if k.startswith("plain/")]
+    assert keys
+    lr = COMPILE["learning_rate"]
+    for k in keys:      # float-atomic summation order differs from run to run: compare against the step size
+        assert np.abs(f["plain/" + k] - f["rccl/" + k]).max() <= 0.05 * lr * 3, k
+    assert np.isfinite(f["allreduce_ms"]).all() and (f["allreduce_ms"] > 0).all()
+
+
+def test_input_pipeline_feeds_the_right_batches():
+    """train() used to hand every step a fresh default-stream tensor that the allocator could recycle
+    while the engine's stream still read it.  Here the dataset is constant per image (image i is all i), batches are
+    gathered on the device from a permutation, the host runs far ahead of the device, and every step's staged input
+    (the handle's xin copy, read back after a sync) must be exactly the batch that was asked for."""
+    name, B, N = "c32nb", 64, 512
+    eng = _engine(name, B)
+    H, W, C = CONFIGS[name]["input_dims"]
+    x = np.broadcast_to((np.arange(N, dtype=np.float32) % 256)[:, None, None, None], (N, H, W, C)).copy()
+    ds = eng.load_dataset(x)
+    assert ds["resident"]
+    order = np.random.default_rng(0).permutation(N)
+    eng.set_permutation(order)
+    from multiscale_variational_autoencoder_amd.initializers import init_params
+    eng.set_params(init_params(eng.param_table, 42))
+    snaps = []
+    for b in range(N // B):
+        xb = eng.gather_batch(b * B, B)
+        eng.train_step(xb, 1e-3, 1000.0, 10.0, 1.0, seed=b)
+        eng.batch_consumed()
+        with eng.torch.cuda.stream(eng.stream):
+            snaps.append(eng.tensor_nosync("xin", B)[:, 0].clone())        # enqueued on the engine's stream: no sync
+    eng.sync()
+    for b, s in enumerate(snaps):
+        assert np.array_equal(s.cpu().numpy(), x[order[b * B:(b + 1) * B], 0, 0, 0]), b
+    # the host-staged variant (dataset "does not fit"): pinned double buffer + copy stream
+    eng2 = _engine(name, B)
+    eng2.set_params(init_params(eng2.param_table, 42))
+    ds2 = eng2.load_dataset(x, resident_fraction=0.0)
+    assert not ds2["resident"]
+    eng2.set_permutation(order)
+    snaps = []
+    for b in range(N // B):
+        xb = eng2.gather_batch(b * B, B)
+        eng2.train_step(xb, 1e-3, 1000.0, 10.0, 1.0, seed=b)
+        eng2.batch_consumed()
+        with eng2.torch.cuda.stream(eng2.stream):
+            snaps.append(eng2.tensor_nosync("xin", B)[:, 0].clone())
+    eng2.sync()
+    for b, s in enumerate(snaps):
+        assert np.array_equal(s.cpu().numpy(), x[order[b * B:(b + 1) * B], 0, 0, 0]), b
+
+
+def test_train_throughput_matches_resident_input_loop():
+    """train() end to end on C32-nb, batch 512: History.history["images_per_sec"] of a steady-state epoch within 10 % of
+    the same engine stepping on one resident batch (what bench.py times)."""
+    from multiscale_variational_autoencoder_amd import MultiscaleVAE
+    cfg = CONFIGS["c32nb"]
+    B, N = 512, 512 * 24
+    x = np.random.default_rng(1).uniform(0, 255, (N,) + tuple(cfg["input_dims"])).astype(np.float32)
+    v = MultiscaleVAE(input_dims=cfg["input_dims"], z_dims=cfg["z_dims"], encoder=cfg["encoder"], decoder=cfg["decoder"])
+    v.compile(learning_rate=1e-3, r_loss_factor=1000, kl_loss_factor=10)
+    hist = v.train(x, batch_size=B, epochs=3, run_folder=None, step_size=1, lr_decay=0.9)
+    ips = hist.history["images_per_sec"]
+    assert hist.history["samples"] == [float(N)] * 3
+    eng = v._engine
+    xd = eng.to_device(x[:B])
+    for i in range(5):
+        eng.train_step(xd, 1e-3, 1000.0, 10.0, 1.0, seed=i)
+    eng.sync()
+    t0 = time.perf_counter()
+    for i in range(24):
+        eng.train_step(xd, 1e-3, 1000.0, 10.0, 1.0, seed=100 + i)
+    eng.sync()
+    ref = 24 * B / (time.perf_counter() - t0)
+    print("train() images/s per epoch:", ips, " resident-input loop:", ref)
+    assert max(ips[1:]) >= 0.9 * ref, (ips, ref)
