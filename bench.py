@@ -60,7 +60,17 @@ def cpu_baseline(wname, seconds=20.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, cores)              # every core this process may run on (a 1-GPU box grants a 16-core share)
+    # a 1-GPU box grants a 16-core share of a much larger host: the affinity mask shows every host core, the cgroup
+    # quota (when readable) the real share -- more threads than that only thrash (uncapped, one step took minutes)
+    quota = 16
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(cores, quota, 64))
     torch.set_num_threads(cores)
     oc = OracleConfig(w["input_dims"], w["z_dims"], encoder=w["encoder"], decoder=w["decoder"])
     P, S = param_table(oc)

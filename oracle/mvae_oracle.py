@@ -235,6 +235,57 @@ class Oracle:
         self.cfg = cfg
         self.dtype = dtype
         self.ptab, self.stab = param_table(cfg)
+        self.kink = None
+
+    # -- subgradient choice at the kinks (ReLU at 0, hard_sigmoid at +-2.5)
+    # A network of this size always has a few units whose pre-activation lies within float32 rounding of a kink (measured:
+    # one ReLU input of 2^-28 in the 64x64 parity case flips with the summation order of the device's float atomics and
+    # moves one weight gradient by 1.7e-3).  Both one-sided derivatives are valid there, and a float32 implementation --
+    # the reference's TensorFlow included -- picks one by rounding.  A parity test can therefore hand the oracle the
+    # ACTIVE SETS the device used (`set_kink_masks`): the oracle then differentiates along the same branch, and reports
+    # how many units disagree with its own float64 active set and how far from the kink they are (the test bounds both).
+    def set_kink_masks(self, masks):
+        """masks: name -> bool array, '<block>.t0' / '.t1' / '.s0' (ReLU active) and '<block>.hsig' (inside the linear
+        part of hard_sigmoid), flat [B, n] or in the tensor's NHWC / [B, C] shape.  None switches the override off."""
+        self.kink = None if masks is None else dict(masks=masks, report=dict(units=0, flips=0, max_abs_at_flip=0.0))
+
+    def kink_report(self):
+        return None if self.kink is None else dict(self.kink["report"])
+
+    def _mask_for(self, name, x):
+        if self.kink is None or name not in self.kink["masks"]:
+            return None
+        m = torch.as_tensor(np.asarray(self.kink["masks"][name]).astype(bool))
+        if x.dim() == 4:
+            m = m.reshape(x.shape[0], x.shape[2], x.shape[3], x.shape[1]).permute(0, 3, 1, 2)
+        else:
+            m = m.reshape(x.shape)
+        return m
+
+    def _account(self, own, m, dist):
+        rep = self.kink["report"]
+        dis = own != m
+        n = int(dis.sum())
+        rep["units"] += own.numel()
+        rep["flips"] += n
+        if n:
+            rep["max_abs_at_flip"] = max(rep["max_abs_at_flip"], float(dist[dis].max()))
+
+    def _relu(self, x, name):
+        m = self._mask_for(name, x)
+        if m is None:
+            return F.relu(x)
+        xd = x.detach()
+        self._account(xd > 0, m, xd.abs())
+        return x * m.to(x.dtype)
+
+    def _hsig(self, u, name):
+        m = self._mask_for(name, u)
+        if m is None:
+            return hard_sigmoid(u)
+        ud = u.detach()
+        self._account((ud >= -2.5) & (ud <= 2.5), m, (ud.abs() - 2.5).abs())
+        return torch.where(m, 0.2 * u + 0.5, hard_sigmoid(ud))
 
     # -- helpers
     def _t(self, a):
@@ -277,10 +328,10 @@ class Oracle:
 
     # -- MobileNetV3 block (layer_blocks.py:556-648 + 418-462)
     def mnv3(self, a, T, p, st, training, group, new_state, inter):
-        t0 = F.relu(conv2d_same(a, T[p + ".conv0.w"], T[p + ".conv0.b"], (1, 1)))
-        t1 = F.relu(depthwise3x3_same(t0, T[p + ".dw.w"], T[p + ".dw.b"]))
+        t0 = self._relu(conv2d_same(a, T[p + ".conv0.w"], T[p + ".conv0.b"], (1, 1)), p + ".t0")
+        t1 = self._relu(depthwise3x3_same(t0, T[p + ".dw.w"], T[p + ".dw.b"]), p + ".t1")
         gap = t1.mean(dim=(2, 3))
-        s0 = F.relu(gap @ T[p + ".se.d0.w"] + T[p + ".se.d0.b"])
+        s0 = self._relu(gap @ T[p + ".se.d0.w"] + T[p + ".se.d0.b"], p + ".s0")
         if training:
             s1, m, v = batchnorm_train(s0, T[p + ".se.bn.gamma"], T[p + ".se.bn.beta"], SE_BN_EPS, (0,), group)
             # 2-D (non fused) path: moving variance from the biased batch variance
@@ -289,11 +340,13 @@ class Oracle:
         else:
             s1 = batchnorm_infer(s0, T[p + ".se.bn.gamma"], T[p + ".se.bn.beta"],
                                  st[p + ".se.bn.mean"], st[p + ".se.bn.var"], SE_BN_EPS)
-        g = hard_sigmoid(s1 @ T[p + ".se.d1.w"] + T[p + ".se.d1.b"])
+        ulin = s1 @ T[p + ".se.d1.w"] + T[p + ".se.d1.b"]
+        g = self._hsig(ulin, p + ".hsig")
         t2 = t1 * g[:, :, None, None]
         out = conv2d_same(t2, T[p + ".conv2.w"], T[p + ".conv2.b"], (1, 1)) + a
         if inter is not None:
             inter[p + ".t0"], inter[p + ".t1"], inter[p + ".g"], inter[p + ".out"] = t0, t1, g, out
+            inter[p + ".s0"], inter[p + ".ulin"] = s0, ulin
         return out
 
     def encode_scale(self, s, band, T, st, eps_s, training, group, new_state, inter):

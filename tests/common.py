@@ -125,3 +125,27 @@ def structurally_zero(ref):
     rms = np.sqrt(sum(float((np.asarray(g, np.float64) ** 2).sum()) for g in ref.values()) /
                   sum(np.asarray(g).size for g in ref.values()))
     return {k for k, g in ref.items() if np.linalg.norm(np.asarray(g, np.float64).ravel()) < 1e-6 * rms * np.sqrt(np.asarray(g).size)}
+
+
+def device_kink_masks(eng, B):
+    """The active sets the device used at every kink of the graph (ReLU outputs > 0, hard_sigmoid inputs inside
+    [-2.5, 2.5]), read back from the saved tensors of the last forward -- see Oracle.set_kink_masks."""
+    masks = {}
+    for k in eng.param_table:
+        if not k.endswith(".mn.conv0.w"):
+            continue
+        p = k[:-len(".conv0.w")]
+        for t in ("t0", "t1", "s0"):
+            masks[p + "." + t] = (eng.tensor(p + "." + t, B) > 0).cpu().numpy()
+        u = eng.tensor(p + ".ulin", B)
+        masks[p + ".hsig"] = ((u >= -2.5) & (u <= 2.5)).cpu().numpy()
+    return masks
+
+
+KINK_MAX_FRACTION = 2e-6     # at most this fraction of the units may sit on the other side of a kink than in the oracle
+KINK_MAX_DISTANCE = 2e-5     # ... and only units this close to the kink (float32 forward error is ~1e-6 of O(1) values)
+
+
+def check_kink_report(rep):
+    assert rep["flips"] <= max(3, KINK_MAX_FRACTION * rep["units"]), rep
+    assert rep["max_abs_at_flip"] <= KINK_MAX_DISTANCE, rep

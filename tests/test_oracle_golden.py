@@ -117,3 +117,43 @@ def test_oracle_gradients_match_finite_differences():
         lm = orc.loss_and_grads(p, *args)[0]["loss"]
         fd = (lp - lm) / (2 * h)
         assert abs(fd - G[name][idx]) <= 1e-4 * max(1.0, abs(fd)), (name, fd, G[name][idx])
+
+
+def test_kink_mask_override_is_the_identity_on_the_oracles_own_active_sets():
+    """Oracle.set_kink_masks (the subgradient choice a GPU parity test hands over): with the oracle's OWN active sets the
+    gradients are unchanged and no unit is reported; flipping one ReLU unit is reported and changes the gradient."""
+    from tests.common import COMPILE, make_inputs, oracle_config
+    from oracle.mvae_oracle import Oracle
+    name, B = "tiny", 4
+    io = make_inputs(name, B)
+    o = Oracle(oracle_config(name))
+    inter = {}
+    args = (io["params"], io["state"], io["x"], io["eps"], io["noise"], io["keep"], COMPILE["r_loss_factor"],
+            COMPILE["kl_loss_factor"])
+    res, G = o.loss_and_grads(*args, inter=inter)
+    masks = {}
+    for k, v in inter.items():
+        a = v.detach().numpy()
+        if a.ndim == 4:
+            a = np.transpose(a, (0, 2, 3, 1))
+        if k.endswith((".t0", ".t1", ".s0")):
+            masks[k] = (a > 0).reshape(B, -1)
+        elif k.endswith(".ulin"):
+            masks[k[:-5] + ".hsig"] = (a >= -2.5) & (a <= 2.5)
+    assert any(k.endswith(".hsig") for k in masks) and any(k.endswith(".s0") for k in masks)
+    o.set_kink_masks(masks)
+    res2, G2 = o.loss_and_grads(*args)
+    rep = o.kink_report()
+    assert rep["flips"] == 0 and rep["units"] > 0
+    assert res2["loss"] == res["loss"]
+    for k in G:
+        assert np.array_equal(G[k], G2[k]), k
+    key = next(k for k in masks if k.endswith(".t0"))
+    flipped = dict(masks)
+    flipped[key] = masks[key].copy()
+    j = int(np.argmax(flipped[key].ravel()))            # an active unit
+    flipped[key].reshape(-1)[j] = False
+    o.set_kink_masks(flipped)
+    res3, G3 = o.loss_and_grads(*args)
+    assert o.kink_report()["flips"] == 1 and o.kink_report()["max_abs_at_flip"] > 0
+    assert any(not np.array_equal(G[k], G3[k]) for k in G)

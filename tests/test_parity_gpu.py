@@ -1,22 +1,31 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on identical inputs, weights
 and injected epsilon / noise / dropout masks.  Tolerances (fp32 kernels vs float64 oracle), BASELINE.md section 5:
 ELBO terms <= 1e-4 relative, reconstructions <= 1e-4 * 255 absolute, gradients per tensor
-||got-ref|| <= max(2e-3 * ||ref||, 2e-4 * rms * sqrt(n)) (tests/common.py:grad_errors; the second arm is the fp32
-cancellation-noise floor of tensors whose true gradient is identically zero)."""
+||got-ref|| <= 2e-4 * max(||ref||, 0.1 * rms * sqrt(n)) (tests/common.py:grad_errors; the second arm is the floor for
+small tensors) and 2e-3 for the tensors whose true gradient is identically zero (a bias that feeds straight into
+BatchNorm: pure fp32 cancellation noise).
+
+The gradient is compared along the device's own branch at every kink (Oracle.set_kink_masks): the device's ReLU /
+hard-sigmoid active sets are read back and the oracle differentiates with them.  Round 1 left an unexplained 1.7e-3
+outlier (dec0.b3.mn.conv0.w, c64nb): tools/grad_stress.py shows ONE ReLU input of 2^-28 in that block flipping with the
+summation order of the forward's float atomics (15 % of the runs), at r_loss_factor = 1000 and batch 2 a single
+pixel-channel moves that 64x64 weight gradient by 1.7e-3.  The number of units that sit on the other side of a kink
+than in the oracle's own float64 forward, and their distance from the kink, are bounded (check_kink_report)."""
 import json
 import os
 
 import numpy as np
 import pytest
 
-from tests.common import (COMPILE, CONFIGS, ROOT, engine_args, grad_errors, make_inputs, oracle_config, reg_grad,
-                          rel_err, structurally_zero)
+from tests.common import (COMPILE, CONFIGS, ROOT, check_kink_report, device_kink_masks, engine_args, grad_errors,
+                          make_inputs, oracle_config, reg_grad, rel_err, structurally_zero)
 
 pytestmark = pytest.mark.gpu
 
 TOL_ELBO = 1e-4
 TOL_RECON_ABS = 1e-4 * 255.0
-TOL_GRAD = 2e-3
+TOL_GRAD = 2e-4            # every tensor whose true gradient is not identically zero
+TOL_GRAD_ZERO = 2e-3       # structurally zero gradients: fp32 cancellation noise over the floor 0.1 * rms * sqrt(n)
 OUT = os.path.join(ROOT, "gpurun_out")
 
 
@@ -31,14 +40,15 @@ def _run_pair(name, B, seed=0):
     oc = oracle_config(name)
     orc = Oracle(oc)
     inter = {}
-    res, G = orc.loss_and_grads(io["params"], io["state"], io["x"], io["eps"], io["noise"], io["keep"],
-                                COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"], inter=inter)
     eng = _engine(name, B)
     eng.set_params(io["params"]); eng.set_state(io["state"])
     d = {k: eng.to_device(io[k]) for k in ("x", "eps", "noise", "keep")}
     out = eng.forward(d["x"], True, d["eps"], d["noise"], d["keep"], outputs=("recon", "mu", "log_var", "z", "losses"))
     eng.backward(COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
     eng.torch.cuda.synchronize()
+    orc.set_kink_masks(device_kink_masks(eng, B))          # differentiate along the device's branch at every kink
+    res, G = orc.loss_and_grads(io["params"], io["state"], io["x"], io["eps"], io["noise"], io["keep"],
+                                COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"], inter=inter)
     return io, oc, orc, res, G, inter, eng, out
 
 
@@ -89,7 +99,12 @@ def test_forward_backward_parity(name, B):
     assert rep["recon_abs"] <= TOL_RECON_ABS, rep["recon_abs"]
     for k in ("loss/r", "loss/r_exp", "loss/kl", "loss/elbo_rel", "loss/reg_rel", "metrics/r", "metrics/kl"):
         assert rep[k] <= TOL_ELBO, (k, rep[k])
-    bad = {k: v for k, v in rep.items() if k.startswith("grad/") and v > TOL_GRAD}
+    kr = orc.kink_report()
+    rep["kink/units"], rep["kink/flips"], rep["kink/max_abs_at_flip"] = kr["units"], kr["flips"], kr["max_abs_at_flip"]
+    _dump(name, rep)
+    check_kink_report(kr)
+    zero = structurally_zero(G)
+    bad = {k: v for k, v in gerr.items() if v > (TOL_GRAD_ZERO if k in zero else TOL_GRAD)}
     assert not bad, (worst, len(bad), dict(list(bad.items())[:12]))
 
 
@@ -197,13 +212,15 @@ def test_c256nb_full_size_parity_and_training():
     name, B = "c256nb", 2
     io = make_inputs(name, B)
     orc = Oracle(oracle_config(name))
-    res, G = orc.loss_and_grads(io["params"], io["state"], io["x"], io["eps"], io["noise"], io["keep"],
-                                COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
     eng = _engine(name, 8)
     eng.set_params(io["params"]); eng.set_state(io["state"])
     d = {k: eng.to_device(io[k]) for k in ("x", "eps", "noise", "keep")}
     out = eng.forward(d["x"], True, d["eps"], d["noise"], d["keep"], outputs=("recon", "losses"))
     eng.backward(COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    orc.set_kink_masks(device_kink_masks(eng, B))
+    res, G = orc.loss_and_grads(io["params"], io["state"], io["x"], io["eps"], io["noise"], io["keep"],
+                                COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    check_kink_report(orc.kink_report())
     losses = out["losses"].cpu().numpy().astype(np.float64)
     elbo = (COMPILE["r_loss_factor"] * losses[:, 1] + COMPILE["kl_loss_factor"] * losses[:, 2]).mean()
     assert abs(elbo - res["data_loss"]) / abs(res["data_loss"]) <= TOL_ELBO
@@ -214,9 +231,9 @@ def test_c256nb_full_size_parity_and_training():
     gerr = grad_errors({k: grads[k].astype(np.float64) + rg[k] for k in G}, G)
     zero = structurally_zero(G)        # biases feeding BatchNorm: pure fp32 cancellation noise, 10x looser bound
     worst = max(((k, v) for k, v in gerr.items() if k not in zero), key=lambda kv: kv[1])
-    # reductions here run over 131072+ rows per tensor: fp32 (atomic) summation noise sets the floor at ~4x the 32x32 bound
-    assert worst[1] <= 4 * TOL_GRAD, worst
-    assert all(gerr[k] <= 10 * TOL_GRAD for k in zero), {k: gerr[k] for k in zero if gerr[k] > 10 * TOL_GRAD}
+    # reductions here run over 131072+ rows per tensor: fp32 (atomic) summation noise, 2.5x the 32x32 bound
+    assert worst[1] <= 2.5 * TOL_GRAD, worst
+    assert all(gerr[k] <= 2 * TOL_GRAD_ZERO for k in zero), {k: gerr[k] for k in zero if gerr[k] > 2 * TOL_GRAD_ZERO}
     x8 = eng.to_device(np.random.default_rng(2).uniform(0, 255, (8, 256, 256, 3)))
     vals = []
     for step in range(8):          # same seed every step: identical noise / dropout draws, so the losses are comparable
@@ -239,8 +256,11 @@ def test_golden_fixture_tiny():
     assert np.abs(out["recon"].cpu().numpy() - f["recon"]).max() <= TOL_RECON_ABS
     assert rel_err(out["losses"].cpu().numpy()[:, :3], f["losses"]) <= TOL_ELBO
     g = eng.get_grads()
-    gerr = grad_errors(g, {k: f["g/" + k] for k in eng.param_table})
-    assert max(gerr.values()) <= TOL_GRAD, max(gerr.items(), key=lambda kv: kv[1])
+    ref = {k: f["g/" + k] for k in eng.param_table}
+    gerr = grad_errors(g, ref)
+    zero = structurally_zero(ref)
+    worst = max(gerr.items(), key=lambda kv: kv[1] / (TOL_GRAD_ZERO if kv[0] in zero else TOL_GRAD))
+    assert worst[1] <= (TOL_GRAD_ZERO if worst[0] in zero else TOL_GRAD), worst
 
 
 def test_device_rng_statistics():

@@ -10,9 +10,9 @@ import time
 import numpy as np
 import pytest
 
-from tests.common import (COMPILE, CONFIGS, engine_args, grad_errors, make_inputs, oracle_config, rel_err,
-                          structurally_zero)
-from tests.test_parity_gpu import TOL_ELBO, TOL_GRAD, TOL_RECON_ABS
+from tests.common import (COMPILE, CONFIGS, check_kink_report, device_kink_masks, engine_args, grad_errors, make_inputs,
+                          oracle_config, rel_err, structurally_zero)
+from tests.test_parity_gpu import TOL_ELBO, TOL_GRAD, TOL_GRAD_ZERO, TOL_RECON_ABS
 
 pytestmark = pytest.mark.gpu
 
@@ -46,8 +46,11 @@ def test_graph_replay_with_device_rng_under_the_oracle(name, B):
     recon = eng.tensor("recon", B).cpu().numpy().reshape(B, H, W, C)
     losses = eng.tensor("losses", B).cpu().numpy().astype(np.float64)
     assert set(np.unique(keep)) <= {0.0, 1.0}
-    res, G = Oracle(oracle_config(name)).loss_and_grads(io["params"], io["state"], io["x"], eps, noise, keep,
-                                                        COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    orc = Oracle(oracle_config(name))
+    orc.set_kink_masks(device_kink_masks(eng, B))
+    res, G = orc.loss_and_grads(io["params"], io["state"], io["x"], eps, noise, keep,
+                                COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    check_kink_report(orc.kink_report())
     elbo = (COMPILE["r_loss_factor"] * losses[:, 1] + COMPILE["kl_loss_factor"] * losses[:, 2]).mean()
     assert abs(elbo - res["data_loss"]) / abs(res["data_loss"]) <= TOL_ELBO
     assert rel_err(losses[:, 0], res["r"]) <= TOL_ELBO and rel_err(losses[:, 3:], res["kl_scale"]) <= TOL_ELBO
@@ -59,14 +62,15 @@ def test_graph_replay_with_device_rng_under_the_oracle(name, B):
     g = eng.get_grads()
     rg = reg_grad(io["params"], eng.param_table)
     gerr = grad_errors({k: g[k].astype(np.float64) + rg[k] for k in G}, G)
-    worst = max(gerr.items(), key=lambda kv: kv[1])
-    assert worst[1] <= TOL_GRAD, worst
+    zero = structurally_zero(G)
+    bad = {k: v for k, v in gerr.items() if v > (TOL_GRAD_ZERO if k in zero else TOL_GRAD)}
+    assert not bad, bad
 
 
 def test_mvae_train_step_abi_equals_the_three_calls():
     """mvae_train_step (the entry INTEGRATION.md binds) == mvae_forward + mvae_backward + mvae_apply_adagrad on the same
-    injected inputs: losses identical bit for bit (deterministic kernels), parameters within float-atomic noise, and
-    both within the oracle bound of test_adagrad_trajectory_parity."""
+    injected inputs: losses and parameters within float-atomic noise of each other (the forward's BatchNorm / pooling
+    sums use float atomics), and both within the oracle bound of test_adagrad_trajectory_parity."""
     from oracle.mvae_oracle import Oracle
     name, B = "c32nb", 4
     io = make_inputs(name, B)
@@ -81,7 +85,7 @@ def test_mvae_train_step_abi_equals_the_three_calls():
         eng.sync()
         runs.append((eng.tensor("losses", B).cpu().numpy().copy(), eng.get_params(), eng.get_state()))
     (la, pa, sa), (lb, pb, sb) = runs
-    assert np.array_equal(la, lb)
+    assert rel_err(la, lb) <= 1e-5
     orc = Oracle(oracle_config(name))
     p0 = {k: np.asarray(v, np.float64) for k, v in io["params"].items()}
     a0 = {k: np.full(v.shape, 0.1) for k, v in p0.items()}
@@ -147,7 +151,7 @@ def test_rccl_allreduce_branch_world1(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     f = np.load(tmp_path / "rccl.npz")
-    assert np.array_equal(f["plain_losses"], f["rccl_losses"])
+    assert rel_err(f["plain_losses"], f["rccl_losses"]) <= 1e-5
     assert float(f["plain_count"]) == float(f["rccl_count"]) == 8.0
     keys = [k[6:] for k in f.files if k.startswith("plain/")]
     assert keys
