@@ -165,6 +165,11 @@ int64_t mvae_profile_report(char* buf, int64_t cap);
 
 /* ---- debugging / parity: look up a saved intermediate of the last forward by name ---- */
 int mvae_tensor_lookup(const mvae_handle* h, const char* name, float** ptr, int64_t* elems_per_image);
+/* ... and its storage type (MVAE_ACT_F32 / MVAE_ACT_BF16: the wide tensors of a bfloat16 scale) */
+int mvae_tensor_lookup2(const mvae_handle* h, const char* name, void** ptr, int64_t* elems_per_image, int32_t* dtype);
+/* storage type a pyramid scale runs in: with MVAE_ACT_BF16 a scale whose shapes the bf16 kernels do not cover (the
+ * 8x8 / 4x4 tops of a deep pyramid) stays float32; the scales only meet in the float32 3-channel pyramid / merge */
+int mvae_scale_dtype(const mvae_handle* h, int32_t scale);
 
 #ifdef __cplusplus
 }

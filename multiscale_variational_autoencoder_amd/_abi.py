@@ -76,6 +76,8 @@ SYMBOLS = {
     "mvae_profile_enable": (C.c_int, [C.c_int32]),
     "mvae_profile_report": (C.c_int64, [C.c_char_p, C.c_int64]),
     "mvae_tensor_lookup": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "mvae_tensor_lookup2": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "mvae_scale_dtype": (C.c_int, [_H, C.c_int32]),
 }
 
 _lib = None

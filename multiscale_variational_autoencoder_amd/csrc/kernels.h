@@ -100,7 +100,7 @@ void launch_colsum(const float* x, float* out, int64_t M, int C, hipStream_t s);
 // vectorised column statistics into slot copies (kernels_opt.hip); mode 0: sum, mode 1: squared deviations from
 // mean = inv_m * (sum of the msl slot copies of msum).  false = shape not covered.
 bool launch_colstat_opt(int mode, const float* x, const float* msum, int msl, float inv_m, float* out, int nslots,
-                        int64_t slot_stride, int64_t M, int C, hipStream_t s);
+                        int64_t slot_stride, int64_t M, int C, hipStream_t s, bool bf = false);
 constexpr int kStatSlots = 16;
 // out[c] += sum_m (x[m,c]-mean[c])^2
 void launch_colsqdev(const float* x, const float* mean, float* out, int64_t M, int C, hipStream_t s);
@@ -195,11 +195,11 @@ void launch_bn2d_mean(const float* sum, const float* mov_mean, float* mean, int6
 
 // ---- edge layers (kernels_edge.hip); return false when the shape is not covered ----
 bool launch_convbase_fwd(const float* in, const float* W, const float* bias, float* out, int B, int H, int Wd, int CI,
-                         int CO, hipStream_t s);
+                         int CO, hipStream_t s, bool bf = false);
 bool launch_convbase_wgrad(const float* in, const float* dy, const float* y, float* dW, float* db, int B, int H, int Wd,
-                           int CI, int CO, GradSlots sl, hipStream_t s);
+                           int CI, int CO, GradSlots sl, hipStream_t s, bool bf = false);
 bool launch_head_fwd(const float* x, const float* scale, const float* shift, const float* W, const float* bias,
-                     float* y, int64_t M, int dc, int C, hipStream_t s);
+                     float* y, int64_t M, int dc, int C, hipStream_t s, bool bf = false);
 // squeeze-excite branch in two forward / two backward launches (kernels_se.hip); part: [se_max_blocks(B)][2][C] floats
 int se_max_blocks(int max_batch);
 bool launch_se_forward(const float* gap, const float* W0, const float* b0, const float* gamma, const float* beta,
@@ -218,31 +218,34 @@ int head_slots();
 // S: [head_slots()][2][dc] floats, zeroed by the caller; adds dW, db (gradient slots), dgamma, dbeta
 bool launch_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,
                      const float* shift, const float* mean, const float* invstd, float* S, float* dW, float* db,
-                     float* dgamma, float* dbeta, float* dout, int64_t M, int dc, int C, GradSlots sl, hipStream_t s);
+                     float* dgamma, float* dbeta, float* dout, int64_t M, int dc, int C, GradSlots sl, hipStream_t s,
+                     bool bf = false);
 // sliding-row depthwise kernels (kernels_dw.hip); false = shape not covered
 // true where the whole-image kernels (k_dw_fwd_img / k_dw_bwd_img, feature maps <= 16 wide) take the launch
 bool dw_uses_img(bool backward, bool mask_in_lsb, int B, int H, int W, int C);
+// bf (here and below): the activation tensors are bfloat16 (act16.h); the pointers then address bf16 elements
 bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* out, float* gap, int B, int H, int W,
-                       int C, hipStream_t s);
+                       int C, hipStream_t s, bool bf = false);
 constexpr int kDwMaxBlocks = 1024;     // partial-sum scratch: kDwMaxBlocks * 10 * C floats
 // mask_in_lsb: dt2 carries the ReLU mask (t1 > 0) in its mantissa LSB (k_gemm_dual conv2 pair) and t1 is not read
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
                          const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
-                         int W, int C, hipStream_t s);
+                         int W, int C, hipStream_t s, bool bf = false);
 // Dense layers around the latent (kernels_dense.hip); false = shape not covered
 bool launch_dense_mu_lv(const float* x, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
-                        float* mu, float* lv, int B, int K, int Z, hipStream_t s);
-bool launch_dense_dz(const float* dy, const float* W, float* dz, int B, int Z, int N, hipStream_t s);
+                        float* mu, float* lv, int B, int K, int Z, hipStream_t s, bool bf = false);
+bool launch_dense_dz(const float* dy, const float* W, float* dz, int B, int Z, int N, hipStream_t s, bool bf = false);
 bool launch_dense_dflat(const float* dmu, const float* dlv, const float* Wmu, const float* Wlv, float* out, int B, int K,
-                        int Z, hipStream_t s);
+                        int Z, hipStream_t s, bool bf = false);
 bool launch_dense_expand(const float* z, const float* W, const float* bias, float* out, int B, int Z, int N,
-                         hipStream_t s);
+                         hipStream_t s, bool bf = false);
 bool launch_dense_wgrad_mu_lv(const float* flat, const float* dmu, const float* dlv, float* dWmu, float* dWlv,
-                              float* dbmu, float* dblv, int B, int K, int Z, hipStream_t s);
+                              float* dbmu, float* dblv, int B, int K, int Z, hipStream_t s, bool bf = false);
 // squeeze-excite backward pair in one launch: dW += a'^T g' (+ db) and dx = g' W^T   (kernels_opt.hip)
 void launch_se_pair(const float* a, const float* g, const float* W, float* dW, float* db, float* dx, int B, int K, int N,
                     const float* a_scale, const float* a_shift, const float* hs_lin, hipStream_t s);
-bool launch_dense_wgrad_dec(const float* z, const float* dy, float* dW, float* db, int B, int Z, int N, hipStream_t s);
+bool launch_dense_wgrad_dec(const float* z, const float* dy, float* dW, float* db, int B, int Z, int N, hipStream_t s,
+                            bool bf = false);
 void launch_add_vec2(float* o0, const float* a0, float* o1, const float* a1, int n, hipStream_t s);
 
 }  // namespace mvae

@@ -1,0 +1,768 @@
+// kernels_bf16.hip -- the MFMA kernels of the MVAE_ACT_BF16 path (BASELINE configs 4-5: 256x256x3, bf16): activations,
+// saved tensors and activation gradients are bfloat16 in HBM, weights / gradients / accumulators float32, products on
+// v_mfma_f32_32x32x16_bf16 (16x the f32-MFMA rate: with half the bytes and f32 MFMAs the 1x1 convolutions of the
+// MobileNetV3 block would be MFMA-bound at today's speed; with bf16 MFMAs every kernel here is bound by memory).
+//
+// Orientation.  All data GEMMs are computed TRANSPOSED: D[row = output channel][col = pixel] = W^T . X^T, i.e. the
+// weights are the A operand (register / LDS resident) and the activation tile the B operand.  Lane l = (r = l & 31,
+// h = l >> 5) then holds, for pixel r, output channels (reg & 3) + 8 (reg >> 2) + 4 h: four CONSECUTIVE channels per
+// register quad -> 8 bytes of the NHWC row, and one v_permlane32_swap per dword turns two quads into 16 contiguous
+// bytes per lane (cdna_hip_programming.md T21): the result leaves as 16-byte stores with no LDS transposition.
+// The B operand of pixel r, k-step kk is channels kk*16 + 8h .. +7 of that pixel = one 16-byte chunk of its row.
+//
+// Weight gradients contract over pixels: both operands are needed pixel-major per channel, which is what
+// ds_read_b64_tr_b16 delivers from a row-major LDS tile (T10): lane (c, h) receives rows 8h .. 8h+7 of channel c.
+#include "kernels.h"
+#include "act16.h"
+#include "prof.h"
+
+namespace mvae {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE_LDS_SYNC16()                                    \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+// 8 floats -> one fragment
+__device__ __forceinline__ bf16x8 frag_of(const float (&v)[8]) {
+  u32x4 u = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+  return as_frag(u);
+}
+__device__ __forceinline__ float act16(float v, int act) {
+  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
+  return v;
+}
+
+// ---- row-major LDS tile of 32 rows x C bf16 (wave private), 16-byte chunks XOR-swizzled -------------------------------
+// C = 64: 128-byte rows, chunk' = chunk ^ (row & 7).  C = 32: two rows share a 128-byte line, chunk8 = (row & 1) * 4 +
+// chunk, chunk8' = chunk8 ^ ((row >> 1) & 7).  Returns the BYTE offset of (row, 16-byte chunk) inside the tile.
+template <int C>
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+  if constexpr (C == 64) return row * 128 + ((chunk ^ (row & 7)) << 4);
+  else return (row >> 1) * 128 + ((((row & 1) * 4 + chunk) ^ ((row >> 1) & 7)) << 4);
+}
+// the wave's 32 x C tile is ONE contiguous run of 32*C*2 bytes in HBM: lane l takes 16-byte chunks l, l + 64, ...
+template <int C>
+struct TileRegs { u32x4 v[C / 16]; };
+template <int C>
+__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ base, int64_t row0, int lane, TileRegs<C>& t) {
+  const u32x4* p = reinterpret_cast<const u32x4*>(base + row0 * C) + lane;
+#pragma unroll
+  for (int j = 0; j < C / 16; ++j) t.v[j] = p[j * 64];
+}
+template <int C>
+__device__ __forceinline__ void tile_store_lds(char* tile, int lane, const TileRegs<C>& t) {
+#pragma unroll
+  for (int j = 0; j < C / 16; ++j) {
+    const int c = j * 64 + lane, row = c / (C / 8), ch = c % (C / 8);
+    *reinterpret_cast<u32x4*>(tile + tile_off<C>(row, ch)) = t.v[j];
+  }
+}
+// B operand of the data GEMM / A operand of a row-major product: pixel (row) r, channels kk*16 + 8h .. +7
+template <int C>
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int r, int h, int kk) {
+  return as_frag(*reinterpret_cast<const u32x4*>(tile + tile_off<C>(r, 2 * kk + h)));
+}
+// transposed fragment: channel ct*32 + r, rows 16 s + 8 h .. + 7   (two ds_read_b64_tr_b16)
+template <int C>
+__device__ __forceinline__ bf16x8 frag_cols(const char* tile, int lane, int ct, int s) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;       // 16-lane group g, its lane 4q + p
+  const int c0 = ct * 32 + 16 * (g & 1) + 4 * p;                    // the 4 channels this lane ADDRESSES
+  const int rb = 16 * s + 8 * (g >> 1);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int o0 = tile_off<C>(rb + q, c0 >> 3) + (c0 & 7) * 2;
+  const int o1 = tile_off<C>(rb + 4 + q, c0 >> 3) + (c0 & 7) * 2;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o1));
+  s16x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, f);
+}
+// acc + sum of the 8 elements.  (v_dot2c_f32_bf16 against (1, 1) would do a pair per instruction, but it returned wrong
+// sums in tools/bf16_unit.hip on gfx950 / ROCm 7.2; two shifts / masks and two adds per dword are cheap next to the
+// tile's memory time.)
+__device__ __forceinline__ float frag_sum(bf16x8 f, float acc) {
+  const u32x4 u = __builtin_bit_cast(u32x4, f);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc += bf16_lo(u[e]) + bf16_hi(u[e]);
+  return acc;
+}
+
+// weights of a 1x1 convolution as A-operand fragments, resident in registers for the whole kernel:
+// wf[nt][kk] = Wm[k = kk*16 + 8h + j][n = nt*32 + r], Wm[k][n] = WT ? W[n*K + k] : W[k*N + n]
+template <int K, int N, bool WT>
+__device__ __forceinline__ void load_wfrags(const float* __restrict__ W, int r, int h, bf16x8 (&wf)[N / 32][K / 16]) {
+#pragma unroll
+  for (int nt = 0; nt < N / 32; ++nt)
+#pragma unroll
+    for (int kk = 0; kk < K / 16; ++kk) {
+      float v[8];
+      const int n = nt * 32 + r, k0 = kk * 16 + 8 * h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = WT ? W[(int64_t)n * K + k0 + j] : W[(int64_t)(k0 + j) * N + n];
+      wf[nt][kk] = frag_of(v);
+    }
+}
+
+// epilogue of a transposed-orientation tile: acc[nt] holds channels nt*32 + 8q + 4h + e (e = reg & 3, q = reg >> 2) of
+// pixel row0 + r.  v = act(acc + bias) + residual, packed to bf16, two quads -> one 16-byte store.  The residual tile
+// was staged in LDS with the same coalesced 16-byte loads as the input (one tile ahead); here it is read back 8 bytes
+// per lane in the accumulator's layout.
+template <int N, bool RES>
+__device__ __forceinline__ void store_tile_t(const f32x16 (&acc)[N / 32], const float* __restrict__ bias, int act,
+                                             const char* __restrict__ res_tile, bf16_t* __restrict__ Y, int64_t row0, int r,
+                                             int h) {
+  const int64_t rowoff = (row0 + r) * N;
+#pragma unroll
+  for (int nt = 0; nt < N / 32; ++nt) {
+    uint2 pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c0 = nt * 32 + 8 * q + 4 * h;
+      f32x4 v = {acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
+      if (bias) v += *reinterpret_cast<const f32x4*>(bias + c0);
+      if (act != ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act16(v[e], act);
+      }
+      if constexpr (RES) v += unpack4(*reinterpret_cast<const uint2*>(res_tile + tile_off<N>(r, c0 >> 3) + (c0 & 7) * 2));
+      pk[q] = pack4(v);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      uint2 a = pk[2 * p], b = pk[2 * p + 1];
+      auto s0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+      auto s1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+      const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+      *reinterpret_cast<u32x4*>(Y + rowoff + nt * 32 + 16 * p + 8 * h) = o;
+    }
+  }
+}
+
+// =================================================================================================
+// Y[M,N] = act( (X * gate[image]) . Wm + bias ) + residual     1x1 convolution (and its transpose), bf16 storage
+// (layer_blocks.py:594-602 conv0, :625-641 conv2, :946-951 the 1x1 Conv2D / Conv2DTranspose of basic_block)
+// block = 4 waves, wave = 32 rows (wave-private LDS tile, no block barrier); M % 32 == 0; gate: rows_per_image % 32 == 0
+// =================================================================================================
+template <int K, int N, bool WT, bool GATE, bool RES>
+__global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, const float* __restrict__ W,
+                                              const float* __restrict__ bias, const float* __restrict__ gate,
+                                              const bf16_t* __restrict__ res, bf16_t* __restrict__ Y, int64_t ntiles,
+                                              int64_t rows_per_image, int act) {
+  constexpr int TB = 32 * K * 2, RB = RES ? 32 * N * 2 : 0;
+  __shared__ __attribute__((aligned(16))) char lds[4 * (TB + RB)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  char* tile = lds + wave * (TB + RB);
+  char* rtile = tile + TB;
+  bf16x8 wf[N / 32][K / 16];
+  load_wfrags<K, N, WT>(W, r, h, wf);
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  TileRegs<K> cur, nxt;
+  TileRegs<RES ? N : 16> rcur, rnxt;
+  if (t < ntiles) {
+    tile_load<K>(X, t * 32, lane, cur);
+    if constexpr (RES) tile_load<N>(res, t * 32, lane, rcur);
+  }
+  for (; t < ntiles; t += stride) {
+    const int64_t row0 = t * 32;
+    const int64_t tn = t + stride < ntiles ? t + stride : t;
+    tile_load<K>(X, tn * 32, lane, nxt);                       // next tile in flight under this tile's work
+    if constexpr (RES) tile_load<N>(res, tn * 32, lane, rnxt);
+    if constexpr (GATE) {
+      // lane's chunks all have channel chunk lane % (K/8): 8 gate values per tile (one image per wave tile)
+      const int64_t img = row0 / rows_per_image;
+      const f32x4* gp = reinterpret_cast<const f32x4*>(gate + img * K + (lane % (K / 8)) * 8);
+      const f32x4 g0 = gp[0], g1 = gp[1];
+#pragma unroll
+      for (int j = 0; j < K / 16; ++j) {
+        const u32x4 u = cur.v[j];
+        float v[8] = {bf16_lo(u[0]) * g0[0], bf16_hi(u[0]) * g0[1], bf16_lo(u[1]) * g0[2], bf16_hi(u[1]) * g0[3],
+                      bf16_lo(u[2]) * g1[0], bf16_hi(u[2]) * g1[1], bf16_lo(u[3]) * g1[2], bf16_hi(u[3]) * g1[3]};
+        cur.v[j] = __builtin_bit_cast(u32x4, frag_of(v));
+      }
+    }
+    WAVE_LDS_SYNC16();                                         // the previous tile's LDS reads are done
+    tile_store_lds<K>(tile, lane, cur);
+    if constexpr (RES) tile_store_lds<N>(rtile, lane, rcur);
+    WAVE_LDS_SYNC16();
+    f32x16 acc[N / 32];
+#pragma unroll
+    for (int nt = 0; nt < N / 32; ++nt) acc[nt] = zero16();
+#pragma unroll
+    for (int kk = 0; kk < K / 16; ++kk) {
+      const bf16x8 xb = frag_rows<K>(tile, r, h, kk);
+#pragma unroll
+      for (int nt = 0; nt < N / 32; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][kk], xb, acc[nt], 0, 0, 0);
+    }
+    store_tile_t<N, RES>(acc, bias, act, rtile, Y, row0, r, h);
+    cur = nxt;
+    if constexpr (RES) rcur = rnxt;
+  }
+}
+
+// =================================================================================================
+// Backward pair of a 1x1 C -> C convolution of the MobileNetV3 block in ONE pass over (X, aux) (layer_blocks.py:594-641
+// inverted; the f32 counterpart is k_gemm_dual):
+//     Y[M,C]  = X . W^T (+ residual)                       W = Conv2D kernel [ci][co]
+//     dW[ci][co] += gate[b,ci] * sum_m aux[m,ci] X[m,co] ;  db[co] += sum_m X[m,co]
+//     dot_out[b,ci] += sum_co W[ci][co] * P_b[ci][co],  P_b = sum_{m in image b} aux[m,ci] X[m,co]
+//         ( = sum_m Y[m,ci] aux[m,ci], the squeeze-excite gate gradient, from the weight-gradient product itself )
+// MODE 1 = conv2 pair (gate + dot, no residual): aux = t1, X = dout.   MODE 2 = conv0 pair (residual): aux = block input,
+// X = dt0.  A wave takes a CONTIGUOUS run of 32-row tiles inside one image, so the ungated P accumulates in registers
+// over the run and the gate scaling / gate gradient cost one pass over the accumulators per wave, not per tile.
+// =================================================================================================
+template <int C, int MODE>
+__global__ void __launch_bounds__(256) k16_dual(const bf16_t* __restrict__ X, const float* __restrict__ W,
+                                                const bf16_t* __restrict__ aux, const float* __restrict__ gate,
+                                                const bf16_t* __restrict__ res, bf16_t* __restrict__ Y,
+                                                float* __restrict__ dW, float* __restrict__ db,
+                                                float* __restrict__ dot_out, int64_t ntiles, int64_t tiles_per_wave,
+                                                int64_t tiles_per_image, int nslots, int64_t slot_stride) {
+  constexpr int CT = C / 32, TB = 32 * C * 2, NTL = MODE == 2 ? 3 : 2;    // tiles per wave in LDS: X, aux (, residual)
+  constexpr int TILES = (4 * NTL * TB > C * C * 4) ? 4 * NTL * TB : C * C * 4;
+  // the data GEMM's weight fragments live in LDS, one 16-byte slot per (fragment, lane): 32 registers less per lane
+  // (C = 64), which is what keeps the residual form under 256 VGPRs = two blocks per CU
+  __shared__ __attribute__((aligned(16))) char lds[TILES + CT * (C / 16) * 64 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  char* tx = lds + wave * (NTL * TB);
+  char* ta = tx + TB;
+  char* tr = ta + TB;
+  u32x4* wfl = reinterpret_cast<u32x4*>(lds + TILES);
+  if (wave == 0) {
+    bf16x8 wf[CT][C / 16];
+    load_wfrags<C, C, true>(W, r, h, wf);                      // Wm[k = co][n = ci] = W[ci*C + co]
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt)
+#pragma unroll
+      for (int kk = 0; kk < C / 16; ++kk) wfl[(nt * (C / 16) + kk) * 64 + lane] = __builtin_bit_cast(u32x4, wf[nt][kk]);
+  }
+  __syncthreads();
+  f32x16 accw[CT][CT];                                         // [nt = co tile][kt = ci tile]: D'[row = co][col = ci]
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int b = 0; b < CT; ++b) accw[a][b] = zero16();
+  float bsum[CT];
+#pragma unroll
+  for (int a = 0; a < CT; ++a) bsum[a] = 0.f;
+  // a wave takes a contiguous run of tiles that lies inside ONE image (launcher: tiles_per_wave divides
+  // tiles_per_image), so the ungated product P = aux^T X accumulates in accw over the whole run; the gate scaling and
+  // the gate gradient are applied once, after the loop
+  const int64_t w_id = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t t0 = w_id * tiles_per_wave;
+  int64_t t1 = t0 + tiles_per_wave;
+  if (t1 > ntiles) t1 = ntiles;
+  TileRegs<C> cx, ca, nx, na;
+  TileRegs<MODE == 2 ? C : 16> cr, nr;
+  if (t0 < t1) {
+    tile_load<C>(X, t0 * 32, lane, cx); tile_load<C>(aux, t0 * 32, lane, ca);
+    if constexpr (MODE == 2) tile_load<C>(res, t0 * 32, lane, cr);
+  }
+  for (int64_t t = t0; t < t1; ++t) {
+    const int64_t row0 = t * 32;
+    const int64_t tn = t + 1 < t1 ? t + 1 : t;
+    tile_load<C>(X, tn * 32, lane, nx);
+    tile_load<C>(aux, tn * 32, lane, na);
+    if constexpr (MODE == 2) tile_load<C>(res, tn * 32, lane, nr);
+    WAVE_LDS_SYNC16();
+    tile_store_lds<C>(tx, lane, cx);
+    tile_store_lds<C>(ta, lane, ca);
+    if constexpr (MODE == 2) tile_store_lds<C>(tr, lane, cr);
+    WAVE_LDS_SYNC16();
+    // ---- Y tile = X . W^T (+ residual)
+    f32x16 acc[CT];
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt) acc[nt] = zero16();
+#pragma unroll
+    for (int kk = 0; kk < C / 16; ++kk) {
+      const bf16x8 xb = frag_rows<C>(tx, r, h, kk);
+#pragma unroll
+      for (int nt = 0; nt < CT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wfl[(nt * (C / 16) + kk) * 64 + lane]), xb, acc[nt], 0, 0, 0);
+    }
+    store_tile_t<C, MODE == 2>(acc, nullptr, ACT_NONE, tr, Y, row0, r, h);
+    // ---- P[co][ci] += X^T aux over the tile's 32 rows
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fa[CT], fb[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) { fa[ct] = frag_cols<C>(tx, lane, ct, s); fb[ct] = frag_cols<C>(ta, lane, ct, s); }
+#pragma unroll
+      for (int nt = 0; nt < CT; ++nt) {
+        bsum[nt] = frag_sum(fa[nt], bsum[nt]);
+#pragma unroll
+        for (int kt = 0; kt < CT; ++kt)
+          accw[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[nt], fb[kt], accw[nt][kt], 0, 0, 0);
+      }
+    }
+    cx = nx; ca = na;
+    if constexpr (MODE == 2) cr = nr;
+  }
+  if constexpr (MODE == 1) {
+    if (t0 < t1) {                                             // wave-uniform
+      const int64_t img = t0 / tiles_per_image;
+#pragma unroll
+      for (int kt = 0; kt < CT; ++kt) {
+        const int ci = kt * 32 + r;
+        const float gl = gate[img * C + ci];
+        float ds = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + (int64_t)ci * C + nt * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              ds += w4[e] * accw[nt][kt][4 * q + e];
+              accw[nt][kt][4 * q + e] *= gl;
+            }
+          }
+        ds += __shfl_xor(ds, 32, 64);
+        if (h == 0) atomicAdd(dot_out + img * C + ci, ds);
+      }
+    }
+  }
+  // ---- reduce the 4 waves' dW through LDS (tile memory is free now), one coalesced atomic set per block
+  float* red = reinterpret_cast<float*>(lds);
+  for (int wv = 0; wv < 4; ++wv) {
+    __syncthreads();
+    if (wave == wv) {
+#pragma unroll
+      for (int nt = 0; nt < CT; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < CT; ++kt)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int co = nt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, ci = kt * 32 + r;
+            const int idx = ci * C + co;
+            red[idx] = (wv == 0 ? 0.f : red[idx]) + accw[nt][kt][reg];
+          }
+    }
+  }
+  __syncthreads();
+  const int64_t slot = (int64_t)(blockIdx.x % nslots) * slot_stride;
+  for (int idx = threadIdx.x; idx < C * C; idx += 256) atomicAdd(&dW[slot + idx], red[idx]);
+  if (db != nullptr) {
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt) {
+      float b = bsum[nt] + __shfl_xor(bsum[nt], 32, 64);
+      if (h == 0) red[wave * C + nt * 32 + r] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < C)
+      atomicAdd(&db[slot + threadIdx.x], red[threadIdx.x] + red[C + threadIdx.x] + red[2 * C + threadIdx.x] + red[3 * C + threadIdx.x]);
+  }
+}
+
+// =================================================================================================
+// k x k strided SAME convolution / transposed convolution (5x5 stride 2 in the notebook blocks), bf16 storage.
+// Same F-form / T-form coordinates as k_conv_taps (kernels_mfma.hip): F: out = small[B,OH,OW,NC=CO], in = big (KC = CI);
+// T: out = big[B,IH,IW,NC=CI], in = small (KC = CO), one sub-pixel phase per blockIdx.y.
+// A 512-thread block keeps the weight slices of ALL taps in LDS as bf16 [tap][n][k] (25 x 4 KB for 32 <-> 64): the tap
+// loop has no barrier.  A wave owns 32 output pixels x NC channels; per tap a lane fetches ITS pixel's KC channels for
+// its k-half straight from global memory (the MFMA B operand is 16 contiguous bytes of the NHWC row; SAME padding = an
+// out-of-range buffer offset, which returns zeros), one tap ahead of the MFMAs.
+// =================================================================================================
+template <int KC, int NC, bool TFORM, int MAXTAPS>
+__global__ void __launch_bounds__(512) k16_taps(const bf16_t* __restrict__ in, const float* __restrict__ W,
+                                                const float* __restrict__ bias, bf16_t* __restrict__ out, ConvGeom g,
+                                                unsigned in_bytes, int tiles_per_wave) {
+  constexpr int NT = NC / 32, KK = KC / 16;
+  __shared__ __attribute__((aligned(16))) char sW[MAXTAPS * NC * KC * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  int py = 0, px = 0, CH = g.OH, CW = g.OW;
+  if (TFORM) {
+    py = blockIdx.y / g.SW; px = blockIdx.y % g.SW;
+    CH = (g.IH - py + g.SH - 1) / g.SH; CW = (g.IW - px + g.SW - 1) / g.SW;
+  }
+  const unsigned Mc = (unsigned)(g.B * CH * CW);
+  const int SHh = TFORM ? g.OH : g.IH, SWw = TFORM ? g.OW : g.IW;      // the tensor the taps read
+  int kh0 = 0, kw0 = 0, khs = 1, kws = 1;
+  if (TFORM) { kh0 = (py + g.PT) % g.SH; kw0 = (px + g.PL) % g.SW; khs = g.SH; kws = g.SW; }
+  const int nkh = kh0 < g.KH ? (g.KH - kh0 + khs - 1) / khs : 0;
+  const int nkw = kw0 < g.KW ? (g.KW - kw0 + kws - 1) / kws : 0;
+  const int ntaps = nkh * nkw;
+  // ---- this phase's weight slices -> LDS, bf16, [tap][n][k] with the 16-byte chunks of a row XOR-swizzled
+  //      F: W[tap][k][n] (Keras HWIO);  T: W[tap][n][k] (the same array read with big = output channels)
+  for (int idx = threadIdx.x; idx < ntaps * NC * KC; idx += 512) {
+    const int tl = idx / (NC * KC), rem = idx % (NC * KC);
+    const int th = tl / nkw, tw = tl % nkw;
+    const int tap = (kh0 + th * khs) * g.KW + kw0 + tw * kws;
+    int n, k;
+    if (TFORM) { n = rem / KC; k = rem % KC; } else { k = rem / NC; n = rem % NC; }
+    const float v = W[(int64_t)tap * NC * KC + rem];
+    const int off = tl * NC * KC * 2 + n * KC * 2 + (((k >> 3) ^ (n & (KC / 8 - 1))) << 4) + (k & 7) * 2;
+    *reinterpret_cast<uint16_t*>(sW + off) = (uint16_t)(pack_bf16(v, 0.f) & 0xFFFFu);
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(in), 0, (int)in_bytes, 0x00020000);
+  const bool pow2 = (CW & (CW - 1)) == 0 && (CH & (CH - 1)) == 0;
+  const int lgw = 31 - __builtin_clz((unsigned)CW), lgh = 31 - __builtin_clz((unsigned)CH);
+  auto split = [&](unsigned p, int& cx, int& cy, int& b) {
+    if (pow2) { cx = (int)(p & (unsigned)(CW - 1)); cy = (int)((p >> lgw) & (unsigned)(CH - 1)); b = (int)(p >> (lgw + lgh)); }
+    else { cx = (int)(p % (unsigned)CW); const unsigned q = p / (unsigned)CW; cy = (int)(q % (unsigned)CH); b = (int)(q / (unsigned)CH); }
+  };
+  float bv[NT][4][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[nt][q][e] = bias ? bias[nt * 32 + 8 * q + 4 * h + e] : 0.f;
+
+  const unsigned wtile0 = ((unsigned)blockIdx.x * 8u + wave) * (unsigned)tiles_per_wave;
+  for (int ti = 0; ti < tiles_per_wave; ++ti) {
+    const unsigned p0 = (wtile0 + ti) * 32u;
+    if (p0 >= Mc) break;                                       // wave-uniform
+    const unsigned p = p0 + r;
+    int cx, cy, b;
+    split(p < Mc ? p : 0u, cx, cy, b);
+    const int y0 = TFORM ? cy : cy * g.SH, x0 = TFORM ? cx : cx * g.SW;
+    const unsigned base = (unsigned)(((b * SHh + y0) * SWw + x0) * KC + 8 * h) * 2u;
+    unsigned inv = p < Mc ? 0u : 0xFFFFu;
+    for (int t = 0; t < nkh; ++t) {
+      const int kh = kh0 + t * khs;
+      const int dy = TFORM ? (py + g.PT - kh) / g.SH : kh - g.PT;
+      if ((unsigned)(y0 + dy) >= (unsigned)SHh) inv |= 1u << t;
+    }
+    for (int t = 0; t < nkw; ++t) {
+      const int kw = kw0 + t * kws;
+      const int dx = TFORM ? (px + g.PL - kw) / g.SW : kw - g.PL;
+      if ((unsigned)(x0 + dx) >= (unsigned)SWw) inv |= 0x100u << t;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+    u32x4 xb[KK], xn[KK];
+    auto fetch = [&](int th, int tw, u32x4 (&dst)[KK]) {
+      const int kh = kh0 + th * khs, kw = kw0 + tw * kws;
+      const int dy = TFORM ? (py + g.PT - kh) / g.SH : kh - g.PT;
+      const int dx = TFORM ? (px + g.PL - kw) / g.SW : kw - g.PL;
+      const unsigned off = (inv & ((1u << th) | (0x100u << tw))) ? 0x80000000u : base + (unsigned)((dy * SWw + dx) * KC * 2);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) dst[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (unsigned)(kk * 32), 0, 0);
+    };
+    if (ntaps > 0) fetch(0, 0, xb);
+    int th = 0, tw = 0;
+    for (int it = 0; it < ntaps; ++it) {
+      if (++tw == nkw) { tw = 0; ++th; }
+      if (it + 1 < ntaps) fetch(th, tw, xn);
+      const char* wt = sW + it * NC * KC * 2;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n = nt * 32 + r;
+          const bf16x8 wa = as_frag(*reinterpret_cast<const u32x4*>(wt + n * KC * 2 + (((2 * kk + h) ^ (n & (KC / 8 - 1))) << 4)));
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, as_frag(xb[kk]), acc[nt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) xb[kk] = xn[kk];
+    }
+    // ---- epilogue: bias, pack, 16-byte stores (pixels past the end are dropped)
+    // (the lane swaps below need every lane: only the store itself is masked)
+    const int64_t opix = TFORM ? ((int64_t)(b * g.IH + (cy * g.SH + py)) * g.IW + (cx * g.SW + px)) : (int64_t)(p < Mc ? p : 0u);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      uint2 pk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[nt][4 * q] + bv[nt][q][0], acc[nt][4 * q + 1] + bv[nt][q][1], acc[nt][4 * q + 2] + bv[nt][q][2],
+                   acc[nt][4 * q + 3] + bv[nt][q][3]};
+        pk[q] = pack4(v);
+      }
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        uint2 a = pk[2 * pp], bb = pk[2 * pp + 1];
+        auto s0 = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
+        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+        if (p < Mc) *reinterpret_cast<u32x4*>(out + opix * NC + nt * 32 + 16 * pp + 8 * h) = o;
+      }
+    }
+  }
+}
+
+// =================================================================================================
+// Weight gradient of a strided SAME convolution (F-form coordinates), bf16 storage:
+//   dW[tap][ci][co] += sum_m big[gather(m, tap)][ci] * small[m][co] ;  db[co] += sum_m small[m][co]
+// One block per (row chunk, kernel row kh) as k_wgrad_taprow: the TG = KW taps of the row share the staged `small` tile
+// (its transposed fragments stay in registers), the gathered `big` tile changes per tap.  1x1 convolutions: TG = 1.
+// D[row = ci][col = co]: A = big^T, B = small, both read with ds_read_b64_tr_b16 from row-major wave-private tiles.
+// =================================================================================================
+template <int CI, int CO, int TG>
+__global__ void __launch_bounds__(256) k16_wgrad(const bf16_t* __restrict__ big, const bf16_t* __restrict__ small,
+                                                 float* __restrict__ dW, float* __restrict__ db, ConvGeom g, int64_t M,
+                                                 int64_t rows_per_block, int nslots, int64_t slot_stride) {
+  constexpr int KT = CI / 32, NT = CO / 32;
+  constexpr int TILE = 32 * (CI + CO) * 2;
+  __shared__ __attribute__((aligned(16))) char lds[(4 * TILE > CI * CO * 4) ? 4 * TILE : CI * CO * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  char* tb = lds + wave * TILE;                   // gathered big tile [32][CI]
+  char* ts = tb + 32 * CI * 2;                    // small tile [32][CO]
+  const int xcd = blockIdx.x & 7, kh = (blockIdx.x >> 3) % g.KH;
+  const uint32_t chunk = ((blockIdx.x >> 3) / g.KH) * 8u + xcd;
+  if ((int64_t)chunk * rows_per_block >= M) return;            // block-uniform, before any barrier
+  f32x16 acc[TG][KT][NT];
+#pragma unroll
+  for (int t = 0; t < TG; ++t)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[t][kt][nt] = zero16();
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+  uint32_t m_begin = chunk * (uint32_t)rows_per_block;
+  uint32_t m_end = m_begin + (uint32_t)rows_per_block;
+  if (m_end > (uint32_t)M) m_end = (uint32_t)M;
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(big), 0,
+      (int)((unsigned)g.B * g.IH * g.IW * CI * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(small), 0,
+      (int)((unsigned)M * CO * 2u), 0x00020000);
+  constexpr int LX = CI / 16, LG = CO / 16;       // 16-byte chunks per lane per tile
+  constexpr int CPX = CI / 8, CPG = CO / 8;       // chunks per pixel
+  const int HWo = g.OH * g.OW;
+  const bool pow2 = (g.OW & (g.OW - 1)) == 0 && (g.OH & (g.OH - 1)) == 0;
+  const int lgw = 31 - __builtin_clz((unsigned)g.OW), lgh = 31 - __builtin_clz((unsigned)g.OH);
+  unsigned pbase[LX];
+  int px0[LX];
+  auto decode = [&](uint32_t row0) {
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+      const int c = j * 64 + lane, pr = c / CPX, ch = c % CPX;
+      const uint32_t m = row0 + pr;
+      int bi, oh, ow;
+      if (pow2) { ow = (int)(m & (uint32_t)(g.OW - 1)); oh = (int)((m >> lgw) & (uint32_t)(g.OH - 1)); bi = (int)(m >> (lgw + lgh)); }
+      else { const uint32_t b = m / (uint32_t)HWo, rem = m - b * (uint32_t)HWo; oh = (int)(rem / (uint32_t)g.OW); ow = (int)(rem - (uint32_t)oh * (uint32_t)g.OW); bi = (int)b; }
+      const int yy = oh * g.SH + kh - g.PT, x0 = ow * g.SW - g.PL;
+      const bool ok = m < m_end && (unsigned)yy < (unsigned)g.IH;
+      pbase[j] = ok ? (unsigned)(((bi * g.IH + yy) * g.IW + x0) * CI + ch * 8) * 2u : 0xC0000000u;
+      px0[j] = x0;
+    }
+  };
+  u32x4 xq[LX], gq[LG];
+  auto load_big = [&](int kw) {
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+      const unsigned off = (unsigned)(px0[j] + kw) < (unsigned)g.IW ? pbase[j] + (unsigned)(kw * CI * 2) : 0x80000000u;
+      xq[j] = __builtin_amdgcn_raw_buffer_load_b128(brs, off, 0, 0);
+    }
+  };
+  auto load_small = [&](uint32_t row0) {
+#pragma unroll
+    for (int j = 0; j < LG; ++j) {
+      const int c = j * 64 + lane, pr = c / CPG, ch = c % CPG;
+      const uint32_t mm = row0 + pr;
+      const unsigned off = mm < m_end ? (mm * CO + ch * 8) * 2u : 0x80000000u;
+      gq[j] = __builtin_amdgcn_raw_buffer_load_b128(srs, off, 0, 0);
+    }
+  };
+  uint32_t row0 = m_begin + wave * 32;
+  if (row0 < m_end) { decode(row0); load_small(row0); load_big(0); }
+  for (; row0 < m_end; row0 += 4 * 32) {
+    WAVE_LDS_SYNC16();
+#pragma unroll
+    for (int j = 0; j < LG; ++j) {
+      const int c = j * 64 + lane;
+      *reinterpret_cast<u32x4*>(ts + tile_off<CO>(c / CPG, c % CPG)) = gq[j];
+    }
+    bf16x8 fs[NT][2];
+    const bool more = row0 + 4 * 32 < m_end;
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      if (t > 0) WAVE_LDS_SYNC16();
+#pragma unroll
+      for (int j = 0; j < LX; ++j) {
+        const int c = j * 64 + lane;
+        *reinterpret_cast<u32x4*>(tb + tile_off<CI>(c / CPX, c % CPX)) = xq[j];
+      }
+      WAVE_LDS_SYNC16();
+      if (t + 1 < TG) load_big(t + 1);
+      else if (more) { decode(row0 + 4 * 32); load_small(row0 + 4 * 32); load_big(0); }
+      if (t == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) { fs[nt][s] = frag_cols<CO>(ts, lane, nt, s); bsum[nt] = frag_sum(fs[nt][s], bsum[nt]); }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const bf16x8 fb = frag_cols<CI>(tb, lane, kt, s);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[t][kt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fs[nt][s], acc[t][kt][nt], 0, 0, 0);
+        }
+    }
+  }
+  float* red = reinterpret_cast<float*>(lds);
+  const int64_t gslot = (int64_t)(blockIdx.x % nslots) * slot_stride;
+#pragma unroll
+  for (int t = 0; t < TG; ++t) {
+    for (int wv = 0; wv < 4; ++wv) {
+      __syncthreads();
+      if (wave == wv) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int ci = kt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+              const int idx = ci * CO + nt * 32 + r;
+              red[idx] = (wv == 0 ? 0.f : red[idx]) + acc[t][kt][nt][reg];
+            }
+      }
+    }
+    __syncthreads();
+    float* dWt = dW + gslot + (int64_t)(kh * g.KW + t) * CI * CO;
+    for (int idx = threadIdx.x; idx < CI * CO; idx += 256) atomicAdd(&dWt[idx], red[idx]);
+  }
+  if (db != nullptr && kh == 0) {
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float b = bsum[nt] + __shfl_xor(bsum[nt], 32, 64);
+      if (h == 0) red[wave * CO + nt * 32 + r] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < CO)
+      atomicAdd(&db[gslot + threadIdx.x], red[threadIdx.x] + red[CO + threadIdx.x] + red[2 * CO + threadIdx.x] + red[3 * CO + threadIdx.x]);
+  }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+static int cus16() { return 256; }
+
+// 1x1 convolution forward / transposed.  false = shape not covered.
+bool launch16_pw(bool transposed, const void* in, const float* w, const float* bias, const float* gate, const void* residual,
+                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s) {
+  if (M % 32 != 0 || M <= 0) return false;
+  if (gate && (rows_per_image % 32 != 0)) return false;
+  const int64_t ntiles = M / 32;
+  const int64_t nblk = (ntiles + 3) / 4;
+  const int grid = (int)(nblk < 4 * cus16() ? nblk : 4 * cus16());
+  const bf16_t* X = (const bf16_t*)in;
+  const bf16_t* R = (const bf16_t*)residual;
+  bf16_t* Y = (bf16_t*)out;
+  ProfScope ps("k16_pw", 2.0 * M * (K + N * (residual ? 2 : 1)), 2.0 * M * K * N, s);
+#define MVAE_PW(KK, NN, WT_)                                                                                          \
+  if (K == KK && N == NN && transposed == WT_) {                                                                      \
+    if (gate && residual) hipLaunchKernelGGL((k16_pw<KK, NN, WT_, true, true>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image, act); \
+    else if (gate) hipLaunchKernelGGL((k16_pw<KK, NN, WT_, true, false>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image, act);       \
+    else if (residual) hipLaunchKernelGGL((k16_pw<KK, NN, WT_, false, true>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image, act);   \
+    else hipLaunchKernelGGL((k16_pw<KK, NN, WT_, false, false>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image, act);                \
+    return true;                                                                                                      \
+  }
+  MVAE_PW(64, 64, false) MVAE_PW(32, 32, false) MVAE_PW(64, 32, false) MVAE_PW(32, 64, false)
+  MVAE_PW(64, 64, true) MVAE_PW(32, 32, true) MVAE_PW(64, 32, true) MVAE_PW(32, 64, true)
+#undef MVAE_PW
+  return false;
+}
+
+// MobileNetV3 backward pair (see k16_dual).  false = shape not covered.
+bool launch16_dual(const void* X, const float* W, const void* aux, const float* gate, const void* residual, void* Y,
+                   float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C, GradSlots sl,
+                   hipStream_t s) {
+  if (M % 32 != 0 || rows_per_image % 32 != 0) return false;
+  const int mode = (gate && dot_out && !residual) ? 1 : ((residual && !gate && !dot_out) ? 2 : 0);
+  if (!mode || (C != 32 && C != 64)) return false;
+  const int64_t ntiles = M / 32, tpi = rows_per_image / 32;
+  // a wave takes a contiguous run of tiles inside ONE image: the largest divisor-by-halving of tiles_per_image that still
+  // leaves >= 8 waves per CU's worth of runs (2 register-limited blocks per CU, several rounds)
+  int64_t tpw = tpi;
+  while (tpw % 2 == 0 && ntiles / tpw < 16 * cus16()) tpw /= 2;
+  while (tpw % 2 == 0 && tpw > 64) tpw /= 2;
+  const int grid = (int)((ntiles / tpw + 3) / 4);
+  ProfScope ps(mode == 1 ? (C == 64 ? "k16_dual<64,1>" : "k16_dual<32,1>") : (C == 64 ? "k16_dual<64,2>" : "k16_dual<32,2>"),
+               2.0 * M * C * (mode == 1 ? 3 : 4), 4.0 * M * C * C, s);
+#define MVAE_D16(CC, MM)                                                                                              \
+  hipLaunchKernelGGL((k16_dual<CC, MM>), dim3(grid), dim3(256), 0, s, (const bf16_t*)X, W, (const bf16_t*)aux, gate,  \
+                     (const bf16_t*)residual, (bf16_t*)Y, sl.at(dW), sl.at(db), dot_out, ntiles, tpw, tpi, sl.count(), sl.stride)
+  if (C == 64) { if (mode == 1) MVAE_D16(64, 1); else MVAE_D16(64, 2); }
+  else { if (mode == 1) MVAE_D16(32, 1); else MVAE_D16(32, 2); }
+#undef MVAE_D16
+  return true;
+}
+
+// k x k convolution (F-form: in = big) / transposed convolution (T-form: in = small).  false = shape not covered.
+bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g,
+                   hipStream_t s) {
+  const int KC = transposed ? g.CO : g.CI, NC = transposed ? g.CI : g.CO;
+  if ((int64_t)g.B * g.IH * g.IW * g.CI * 2 >= (1LL << 31) || (int64_t)g.B * g.OH * g.OW * g.CO * 2 >= (1LL << 31)) return false;
+  if (g.KH > 8 || g.KW > 8 || g.KH * g.KW > 25) return false;
+  if (!((KC == 32 && NC == 64) || (KC == 64 && NC == 32))) return false;
+  int64_t Mc;
+  int classes = 1;
+  if (transposed) { classes = g.SH * g.SW; Mc = (int64_t)g.B * ((g.IH + g.SH - 1) / g.SH) * ((g.IW + g.SW - 1) / g.SW); }
+  else Mc = (int64_t)g.B * g.OH * g.OW;
+  const unsigned in_bytes = (unsigned)((int64_t)g.B * (transposed ? g.OH * g.OW : g.IH * g.IW) * KC * 2);
+  const int64_t tiles = (Mc + 31) / 32;
+  int64_t waves = (int64_t)8 * cus16() / classes;              // one 512-thread block per CU (100 KB of weight slices)
+  if (waves < 8) waves = 8;
+  if (waves > tiles) waves = tiles;
+  const int tpw = (int)((tiles + waves - 1) / waves);
+  const unsigned gx = (unsigned)(((tiles + tpw - 1) / tpw + 7) / 8);
+  ProfScope ps(transposed ? "k16_taps<T>" : "k16_taps<F>", 2.0 * ((double)g.B * g.IH * g.IW * g.CI + (double)g.B * g.OH * g.OW * g.CO),
+               2.0 * g.B * g.OH * g.OW * g.CO * g.KH * g.KW * g.CI, s);
+#define MVAE_T16(A, B_, TF)                                                                                           \
+  hipLaunchKernelGGL((k16_taps<A, B_, TF, 25>), dim3(gx, classes), dim3(512), 0, s, (const bf16_t*)in, w, bias,       \
+                     (bf16_t*)out, g, in_bytes, tpw)
+  if (KC == 32 && NC == 64) { if (transposed) MVAE_T16(32, 64, true); else MVAE_T16(32, 64, false); }
+  else { if (transposed) MVAE_T16(64, 32, true); else MVAE_T16(64, 32, false); }
+#undef MVAE_T16
+  return true;
+}
+
+// convolution weight (+ bias) gradient.  false = shape not covered.
+bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s) {
+  const int64_t M = (int64_t)g.B * g.OH * g.OW;
+  if (M * g.CO * 2 >= (1ll << 31) || (int64_t)g.B * g.IH * g.IW * g.CI * 2 >= (1ll << 31)) return false;
+  if (!((g.CI == 32 && g.CO == 64) || (g.CI == 64 && g.CO == 32))) return false;
+  const bool pointwise = g.KH == 1 && g.KW == 1 && g.SH == 1 && g.SW == 1;
+  if (!pointwise && g.KW != 5) return false;
+  int64_t chunks = 8 * (64 / g.KH);
+  int64_t rpb = (M + chunks - 1) / chunks;
+  rpb = (rpb + 127) / 128 * 128;
+  if (rpb < 128) rpb = 128;
+  chunks = (M + rpb - 1) / rpb;
+  const unsigned groups = (unsigned)((chunks + 7) / 8);
+  if (!pointwise) sl = GradSlots();                            // only small gradients go through the slots
+  ProfScope ps(pointwise ? "k16_wgrad<1x1>" : "k16_wgrad<5x5>", 2.0 * ((double)g.B * g.IH * g.IW * g.CI + (double)M * g.CO),
+               2.0 * M * g.CO * g.KH * g.KW * g.CI, s);
+#define MVAE_W16(A, B_, TG)                                                                                           \
+  hipLaunchKernelGGL((k16_wgrad<A, B_, TG>), dim3(groups * 8u * g.KH), dim3(256), 0, s, (const bf16_t*)big,           \
+                     (const bf16_t*)small, sl.at(dW), sl.at(db), g, M, rpb, sl.count(), sl.stride)
+  if (g.CI == 32) { if (pointwise) MVAE_W16(32, 64, 1); else MVAE_W16(32, 64, 5); }
+  else { if (pointwise) MVAE_W16(64, 32, 1); else MVAE_W16(64, 32, 5); }
+#undef MVAE_W16
+  return true;
+}
+
+}  // namespace mvae

@@ -6,6 +6,7 @@
 //   k_dense_expand  out[b,n]   = bias[n] + sum_k z[b,k] W[k,n]                  (16-byte stores, 4 batch rows per block)
 //   k_outer_wide2   dWmu[k,j], dWlv[k,j] += sum_b flat[b,k] * {dmu,dlv}[b,j]    (flat is read once for both)
 #include "kernels.h"
+#include "act16.h"
 
 namespace mvae {
 
@@ -14,8 +15,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // one wave = 32 batch rows x (up to) 32 output columns x KC reduction indices; lane half h owns [h*KC/2, (h+1)*KC/2).
 // NT = false: Wx stored [K][Nx] (Dense kernel as in Keras);  NT = true: Wx stored [Nx][K] (its transpose use).
-template <bool NT>
-__global__ void __launch_bounds__(256) k_skinny_mfma(const float* __restrict__ A, const float* __restrict__ W1,
+template <bool NT, typename T>
+__global__ void __launch_bounds__(256) k_skinny_mfma(const T* __restrict__ A, const float* __restrict__ W1,
                                                      const float* __restrict__ W2, const float* __restrict__ bias1,
                                                      const float* __restrict__ bias2, float* __restrict__ out1,
                                                      float* __restrict__ out2, int B, int K, int N1, int N2, int KC,
@@ -37,12 +38,12 @@ __global__ void __launch_bounds__(256) k_skinny_mfma(const float* __restrict__ A
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const float* arow = A + (int64_t)row * K;
+  const V4<T> arow(A + (int64_t)(rv ? row : 0) * K);
   for (int q = 0; q < half; q += 4) {
     const int k = kbeg + q;
     f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
     if (k < K) {                                           // K % 4 == 0: a float4 is inside or outside as a whole
-      if (rv) a4 = *reinterpret_cast<const f32x4*>(arow + k);
+      if (rv) a4 = arow[k / 4];
       if (Wc) {
         if (NT) b4 = *reinterpret_cast<const f32x4*>(Wc + (int64_t)jx * K + k);
         else {
@@ -69,8 +70,8 @@ __global__ void __launch_bounds__(256) k_skinny_mfma(const float* __restrict__ A
 // indices, wave w takes 64 of them (lane half h: 32), issues ALL its loads as one batch (8 x 16 B of its A row, the 32
 // matching B values), then runs its 32 MFMAs; the 4 waves' tiles are summed through LDS and leave as ONE atomic set per
 // block.  The looped kernel above waited out a full memory round trip per 4 MFMAs (B = 512, K = 8192: 32 trips, 38 us).
-template <bool NT>
-__global__ void __launch_bounds__(256) k_skinny_mfma256(const float* __restrict__ A, const float* __restrict__ W1,
+template <bool NT, typename T>
+__global__ void __launch_bounds__(256) k_skinny_mfma256(const T* __restrict__ A, const float* __restrict__ W1,
                                                         const float* __restrict__ W2, const float* __restrict__ bias1,
                                                         const float* __restrict__ bias2, float* __restrict__ out1,
                                                         float* __restrict__ out2, int B, int K, int N1, int N2,
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(256) k_skinny_mfma256(const float* __restrict_
   const int jx = two ? i - N1 : (i < N1 ? i : 0);
   f32x4 a4[8];
   float bq[32];
-  const f32x4* ap = reinterpret_cast<const f32x4*>(A + (int64_t)rowc * K + k0);
+  const V4<T> ap(A + (int64_t)rowc * K + k0);
 #pragma unroll
   for (int q = 0; q < 8; ++q) a4[q] = ap[q];
   if (NT) {
@@ -132,9 +133,10 @@ __global__ void __launch_bounds__(256) k_skinny_mfma256(const float* __restrict_
 // RB batch rows per block: the two [K, Z] weight matrices are re-read B / RB times (4 rows per block made that 16 times,
 // 1 GB of L2 traffic, for the 524288 x 16 heads of the 256 x 256 configuration: 268 us)
 constexpr int kDflatRows = 16;
+template <typename T>
 __global__ void __launch_bounds__(256) k_dense_bwd2(const float* __restrict__ g1, const float* __restrict__ g2,
                                                     const float* __restrict__ W1, const float* __restrict__ W2,
-                                                    float* __restrict__ out, int B, int K, int Z) {
+                                                    T* __restrict__ out, int B, int K, int Z) {
   constexpr int RB = kDflatRows;
   __shared__ float sg[RB][64];
   const int b0 = blockIdx.y * RB;
@@ -170,11 +172,12 @@ __global__ void __launch_bounds__(256) k_dense_bwd2(const float* __restrict__ g1
   }
 #pragma unroll
   for (int r = 0; r < RB; ++r)
-    if (b0 + r < B) out[(int64_t)(b0 + r) * K + k] = acc[r];
+    if (b0 + r < B) st1(out, (int64_t)(b0 + r) * K + k, acc[r]);
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256) k_dense_expand(const float* __restrict__ z, const f32x4* __restrict__ W,
-                                                      const f32x4* __restrict__ bias, f32x4* __restrict__ out, int B,
+                                                      const f32x4* __restrict__ bias, const V4<T> out, int B,
                                                       int Z, int N4) {
   __shared__ float sz[4][32];
   const int b0 = blockIdx.y * 4;
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(256) k_dense_expand(const float* __restrict__ 
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    if (b0 + r < B) out[(int64_t)(b0 + r) * N4 + n4] = acc[r];
+    if (b0 + r < B) out.st((int64_t)(b0 + r) * N4 + n4, acc[r]);
 }
 
 // dW1[w][j] += sum_b wide[b,w] s1[b,j] ; dW2[w][j] += sum_b wide[b,w] s2[b,j] ; db1[j] += sum_b s1 ; db2 likewise
@@ -248,7 +251,8 @@ __global__ void __launch_bounds__(256) k_outer_wide2(const float* __restrict__ w
 // MFMA form of the same gradient: a wave owns K-slice [k0, k0+32) and all 2Z <= 32 columns; D[i = k][j] accumulates
 // over the batch two rows per instruction (lane half h takes row b + h).  Operands are channel-on-lane, so the
 // loads are 128-byte row segments; the wave owns its outputs: plain stores, deterministic.
-__global__ void __launch_bounds__(256) k_dense_wgrad_mfma(const float* __restrict__ flat, const float* __restrict__ g1,
+template <typename T>
+__global__ void __launch_bounds__(256) k_dense_wgrad_mfma(const T* __restrict__ flat, const float* __restrict__ g1,
                                                           const float* __restrict__ g2, float* __restrict__ dW1,
                                                           float* __restrict__ dW2, float* __restrict__ db1,
                                                           float* __restrict__ db2, int B, int K, int Z) {
@@ -270,7 +274,7 @@ __global__ void __launch_bounds__(256) k_dense_wgrad_mfma(const float* __restric
   const int bb = wave * per, be = min(B, bb + per);
   // unconditional (clamped) loads, masked by multiplication: the compiler can then issue a whole unrolled batch of
   // loads ahead of its MFMAs instead of one exec-masked load -> wait -> MFMA chain per row pair
-  const float* pa = flat + (kv ? k0 + i : 0);
+  const T* pa = flat + (kv ? k0 + i : 0);
   const float* pg = gsrc + (jv ? jx : 0);
   const float ma = kv ? 1.f : 0.f, mg = jv ? 1.f : 0.f;
   for (int b = bb; b < be; b += 16) {                // 8 row pairs per trip, all 16 loads issued before the MFMAs
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(256) k_dense_wgrad_mfma(const float* __restric
       const int row = b + 2 * u + h;
       rm[u] = row < be ? 1.f : 0.f;
       const int rc = row < be ? row : bb;
-      a[u] = pa[(int64_t)rc * K];
+      a[u] = ld1(pa, (int64_t)rc * K);
       g[u] = pg[(int64_t)rc * Z];
     }
     __builtin_amdgcn_sched_barrier(0);               // raw loads above, every use below
@@ -310,7 +314,8 @@ __global__ void __launch_bounds__(256) k_dense_wgrad_mfma(const float* __restric
 
 // decoder Dense weight gradient on the MFMA: dW[k][n] += sum_b z[b,k] dy[b,n] (k < Z <= 32), db[n] += sum_b dy[b,n].
 // block = one 32-wide slice of N; its 4 waves split the batch; D[i = k][j = n]; plain stores (the block owns its slice).
-__global__ void __launch_bounds__(256) k_dense_wgrad_mfma_t(const float* __restrict__ z, const float* __restrict__ dy,
+template <typename T>
+__global__ void __launch_bounds__(256) k_dense_wgrad_mfma_t(const float* __restrict__ z, const T* __restrict__ dy,
                                                             float* __restrict__ dW, float* __restrict__ db, int B,
                                                             int Z, int N) {
   __shared__ float red[4][16][64];
@@ -326,7 +331,7 @@ __global__ void __launch_bounds__(256) k_dense_wgrad_mfma_t(const float* __restr
   const int per = ((B + 7) / 8) * 2;
   const int bb = wave * per, be = min(B, bb + per);
   const float* pa = z + (kv ? i : 0);
-  const float* pg = dy + (nv ? n0 + i : 0);
+  const T* pg = dy + (nv ? n0 + i : 0);
   const float ma = kv ? 1.f : 0.f, mg = nv ? 1.f : 0.f;
   for (int b = bb; b < be; b += 16) {                // clamped loads + multiplicative masks: see k_dense_wgrad_mfma
     float a[8], g[8], rm[8];
@@ -336,7 +341,7 @@ __global__ void __launch_bounds__(256) k_dense_wgrad_mfma_t(const float* __restr
       rm[u] = row < be ? 1.f : 0.f;
       const int rc = row < be ? row : bb;
       a[u] = pa[(int64_t)rc * Z];
-      g[u] = pg[(int64_t)rc * N];
+      g[u] = ld1(pg, (int64_t)rc * N);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -362,15 +367,16 @@ __global__ void __launch_bounds__(256) k_dense_wgrad_mfma_t(const float* __restr
 }
 
 // ---- launchers; false = shape not covered ---------------------------------------------------------------------
-static void run_skinny(bool nt, const float* A, const float* W1, const float* W2, const float* b1, const float* b2,
+template <typename T>
+static void run_skinny(bool nt, const T* A, const float* W1, const float* W2, const float* b1, const float* b2,
                        float* o1, float* o2, int B, int K, int N1, int N2, hipStream_t s) {
   launch_zero(o1, (int64_t)B * N1, s);
   if (N2) launch_zero(o2, (int64_t)B * N2, s);
   if (K % 256 == 0 && N1 >= 1) {
     const int ngroups = K / 256;
     dim3 grid((unsigned)(((B + 31) / 32) * ngroups));
-    if (nt) hipLaunchKernelGGL(k_skinny_mfma256<true>, grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, ngroups);
-    else hipLaunchKernelGGL(k_skinny_mfma256<false>, grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, ngroups);
+    if (nt) hipLaunchKernelGGL((k_skinny_mfma256<true, T>), grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, ngroups);
+    else hipLaunchKernelGGL((k_skinny_mfma256<false, T>), grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, ngroups);
     return;
   }
   int KC = 256;
@@ -378,44 +384,54 @@ static void run_skinny(bool nt, const float* A, const float* W1, const float* W2
   const int nchunks = (K + KC - 1) / KC;
   const int64_t waves = (int64_t)((B + 31) / 32) * nchunks;
   dim3 grid((unsigned)((waves + 3) / 4));
-  if (nt) hipLaunchKernelGGL(k_skinny_mfma<true>, grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, KC, nchunks);
-  else hipLaunchKernelGGL(k_skinny_mfma<false>, grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, KC, nchunks);
+  if (nt) hipLaunchKernelGGL((k_skinny_mfma<true, T>), grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, KC, nchunks);
+  else hipLaunchKernelGGL((k_skinny_mfma<false, T>), grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, KC, nchunks);
 }
 
 // mu = x Wmu + bmu ; lv = x Wlv + blv   (x [B,K], W [K,Z])
 bool launch_dense_mu_lv(const float* x, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
-                        float* mu, float* lv, int B, int K, int Z, hipStream_t s) {
+                        float* mu, float* lv, int B, int K, int Z, hipStream_t s, bool bf) {
   if (2 * Z > 32 || K < 256 || (K % 4)) return false;
-  run_skinny(false, x, Wmu, Wlv, bmu, blv, mu, lv, B, K, Z, Z, s);
+  if (bf) run_skinny<bf16_t>(false, (const bf16_t*)x, Wmu, Wlv, bmu, blv, mu, lv, B, K, Z, Z, s);
+  else run_skinny<float>(false, x, Wmu, Wlv, bmu, blv, mu, lv, B, K, Z, Z, s);
   return true;
 }
 // dz[b,k] = sum_n dy[b,n] W[k,n]   (W [Z,N])
-bool launch_dense_dz(const float* dy, const float* W, float* dz, int B, int Z, int N, hipStream_t s) {
+bool launch_dense_dz(const float* dy, const float* W, float* dz, int B, int Z, int N, hipStream_t s, bool bf) {
   if (Z > 32 || N < 256 || (N % 4)) return false;
-  run_skinny(true, dy, W, nullptr, nullptr, nullptr, dz, nullptr, B, N, Z, 0, s);
+  if (bf) run_skinny<bf16_t>(true, (const bf16_t*)dy, W, nullptr, nullptr, nullptr, dz, nullptr, B, N, Z, 0, s);
+  else run_skinny<float>(true, dy, W, nullptr, nullptr, nullptr, dz, nullptr, B, N, Z, 0, s);
   return true;
 }
 bool launch_dense_dflat(const float* dmu, const float* dlv, const float* Wmu, const float* Wlv, float* out, int B, int K,
-                        int Z, hipStream_t s) {
+                        int Z, hipStream_t s, bool bf) {
   if (2 * Z > 64) return false;
-  hipLaunchKernelGGL(k_dense_bwd2, dim3((K + 255) / 256, (B + kDflatRows - 1) / kDflatRows), dim3(256), 0, s, dmu, dlv, Wmu, Wlv, out, B, K, Z);
+  const dim3 grid((K + 255) / 256, (B + kDflatRows - 1) / kDflatRows);
+  if (bf) hipLaunchKernelGGL(k_dense_bwd2<bf16_t>, grid, dim3(256), 0, s, dmu, dlv, Wmu, Wlv, (bf16_t*)out, B, K, Z);
+  else hipLaunchKernelGGL(k_dense_bwd2<float>, grid, dim3(256), 0, s, dmu, dlv, Wmu, Wlv, out, B, K, Z);
   return true;
 }
 bool launch_dense_expand(const float* z, const float* W, const float* bias, float* out, int B, int Z, int N,
-                         hipStream_t s) {
+                         hipStream_t s, bool bf) {
   if (Z > 32 || (N % 4)) return false;
-  hipLaunchKernelGGL(k_dense_expand, dim3((N / 4 + 255) / 256, (B + 3) / 4), dim3(256), 0, s, z, (const f32x4*)W,
-                     (const f32x4*)bias, (f32x4*)out, B, Z, N / 4);
+  const dim3 grid((N / 4 + 255) / 256, (B + 3) / 4);
+  if (bf) hipLaunchKernelGGL(k_dense_expand<bf16_t>, grid, dim3(256), 0, s, z, (const f32x4*)W, (const f32x4*)bias,
+                             V4<bf16_t>((bf16_t*)out), B, Z, N / 4);
+  else hipLaunchKernelGGL(k_dense_expand<float>, grid, dim3(256), 0, s, z, (const f32x4*)W, (const f32x4*)bias,
+                          V4<float>(out), B, Z, N / 4);
   return true;
 }
 bool launch_dense_wgrad_mu_lv(const float* flat, const float* dmu, const float* dlv, float* dWmu, float* dWlv,
-                              float* dbmu, float* dblv, int B, int K, int Z, hipStream_t s) {
+                              float* dbmu, float* dblv, int B, int K, int Z, hipStream_t s, bool bf) {
   if (2 * Z > 32) return false;
   if (K >= 64) {
-    hipLaunchKernelGGL(k_dense_wgrad_mfma, dim3((K + 31) / 32), dim3(256), 0, s, flat, dmu, dlv, dWmu, dWlv, dbmu,
-                       dblv, B, K, Z);
+    if (bf) hipLaunchKernelGGL(k_dense_wgrad_mfma<bf16_t>, dim3((K + 31) / 32), dim3(256), 0, s, (const bf16_t*)flat, dmu, dlv,
+                               dWmu, dWlv, dbmu, dblv, B, K, Z);
+    else hipLaunchKernelGGL(k_dense_wgrad_mfma<float>, dim3((K + 31) / 32), dim3(256), 0, s, flat, dmu, dlv, dWmu, dWlv, dbmu,
+                            dblv, B, K, Z);
     return true;
   }
+  if (bf) return false;
   int bpc = B >= 512 ? 64 : (B >= 64 ? 32 : B);
   if (bpc < 1) bpc = 1;
   hipLaunchKernelGGL(k_outer_wide2, dim3((K + 255) / 256, (B + bpc - 1) / bpc), dim3(256), 0, s, flat, dmu, dlv, dWmu,
@@ -424,9 +440,11 @@ bool launch_dense_wgrad_mu_lv(const float* flat, const float* dmu, const float* 
 }
 
 // dW[k][n] += sum_b z[b,k] dy[b,n] ; db[n] += sum_b dy[b,n]     (decoder Dense, multiscale_vae.py:402-406)
-bool launch_dense_wgrad_dec(const float* z, const float* dy, float* dW, float* db, int B, int Z, int N, hipStream_t s) {
+bool launch_dense_wgrad_dec(const float* z, const float* dy, float* dW, float* db, int B, int Z, int N, hipStream_t s,
+                            bool bf) {
   if (Z > 32 || N < 256) return false;
-  hipLaunchKernelGGL(k_dense_wgrad_mfma_t, dim3((N + 31) / 32), dim3(256), 0, s, z, dy, dW, db, B, Z, N);
+  if (bf) hipLaunchKernelGGL(k_dense_wgrad_mfma_t<bf16_t>, dim3((N + 31) / 32), dim3(256), 0, s, z, (const bf16_t*)dy, dW, db, B, Z, N);
+  else hipLaunchKernelGGL(k_dense_wgrad_mfma_t<float>, dim3((N + 31) / 32), dim3(256), 0, s, z, dy, dW, db, B, Z, N);
   return true;
 }
 

@@ -6,6 +6,7 @@
 //             dt0 = dwT(d1) * (t0 > 0) ;  dW[a][e][c] += sum t0 * d1(shifted) ;  db[c] += sum d1
 // replacing five separate full-tensor launches (dw_fwd, spatial_sum; mn_dt1pre, dw_wgrad, dw_bwd_data).
 #include "kernels.h"
+#include "act16.h"
 
 namespace mvae {
 
@@ -17,9 +18,9 @@ struct DwGeom { int H, W, C4, XS, strips; };
 // ring[slot][xs][c4] as float4, xs in [0, XS + 2): column xs <-> image column x0 - 1 + xs
 #define RING(slot, xs, c4) ring[((slot) * XSP + (xs)) * g.C4 + (c4)]
 
-template <bool FUSE_GAP>
-__global__ void __launch_bounds__(256) k_dw_fwd_ring(const f32x4* __restrict__ in, const f32x4* __restrict__ w,
-                                                     const f32x4* __restrict__ bias, f32x4* __restrict__ out,
+template <bool FUSE_GAP, typename T>
+__global__ void __launch_bounds__(256) k_dw_fwd_ring(const V4<T> in, const f32x4* __restrict__ w,
+                                                     const f32x4* __restrict__ bias, const V4<T> out,
                                                      float* __restrict__ gap, DwGeom g, float inv_hw) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   f32x4* ring = reinterpret_cast<f32x4*>(dyn_lds);
@@ -32,30 +33,31 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const f32x4* __restrict__ i
 #pragma unroll
   for (int k = 0; k < 9; ++k) wt[k] = w[k * g.C4 + c4];
   const f32x4 bs = bias[c4];
-  const f32x4* img = in + (int64_t)b * g.H * g.W * g.C4;
-  f32x4* oimg = out + (int64_t)b * g.H * g.W * g.C4;
+  const V4<T> img = in + (int64_t)b * g.H * g.W * g.C4;
+  const V4<T> oimg = out + (int64_t)b * g.H * g.W * g.C4;
   const int row_items = XSP * g.C4;
 
   // Rows travel HBM -> registers -> LDS ring.  A row is fetched FOUR iterations before it is stored to the ring (a
   // register FIFO of four rows, statically indexed by unrolling the row loop by four): with one or two resident blocks
   // per CU the bytes in flight per CU -- not the arithmetic -- set the rate of this kernel.
-  f32x4 rv[4][3];
-  auto fetch_row = [&](int y, f32x4 (&r)[3]) {
+  typedef typename V4<T>::raw raw_t;
+  raw_t rv[4][3];
+  auto fetch_row = [&](int y, raw_t (&r)[3]) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int t = threadIdx.x + 256 * u;
       const int x = x0 - 1 + t / g.C4;
       const bool ok = t < row_items && x >= 0 && x < g.W;
-      r[u] = img[ok ? ((int64_t)y * g.W + x) * g.C4 + c4 : 0];               // RAW: clamped, unconditional
+      r[u] = img.ld(ok ? ((int64_t)y * g.W + x) * g.C4 + c4 : 0);            // RAW: clamped, unconditional, unconverted
     }
   };
-  auto store_row = [&](int y, const f32x4 (&r)[3]) {  // row y (with column halo) -> ring slot y & 3; halo zeroed here
+  auto store_row = [&](int y, const raw_t (&r)[3]) {  // row y (with column halo) -> ring slot y & 3; halo zeroed here
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int t = threadIdx.x + 256 * u;
       const int x = x0 - 1 + t / g.C4;
       const bool ok = x >= 0 && x < g.W;
-      if (t < row_items) RING(y & 3, t / g.C4, c4) = ok ? r[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < row_items) RING(y & 3, t / g.C4, c4) = ok ? V4<T>::cv(r[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   f32x4 gsum[2];
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const f32x4* __restrict__ i
               }
 #pragma unroll
               for (int q = 0; q < 4; ++q) acc[q] = acc[q] > 0.f ? acc[q] : 0.f;
-              oimg[((int64_t)y * g.W + x0 + xl) * g.C4 + c4] = acc;
+              oimg.st(((int64_t)y * g.W + x0 + xl) * g.C4 + c4, acc);
               if (FUSE_GAP) gsum[k] += acc;
             }
           }
@@ -129,17 +131,17 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const f32x4* __restrict__ i
 // x ~2.5 us needs ~50 KB per CU).  Here a block takes IPB = 256 / (H * C4) whole images (256 * W float4 = W loads per
 // thread, all issued at once), and thread (image, y, c4) then walks its output row with a 3x3 register window fed from
 // LDS.  One memory round trip per image instead of a pipeline of H of them; the GAP needs no atomics.
-template <int W_, int C4>
-__global__ void __launch_bounds__(256, 2) k_dw_fwd_img(const f32x4* __restrict__ in, const f32x4* __restrict__ w,
-                                                       const f32x4* __restrict__ bias, f32x4* __restrict__ out,
+template <int W_, int C4, typename T>
+__global__ void __launch_bounds__(256, 2) k_dw_fwd_img(const V4<T> in, const f32x4* __restrict__ w,
+                                                       const f32x4* __restrict__ bias, const V4<T> out,
                                                        float* __restrict__ gap, int H, float inv_hw) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   f32x4* tile = reinterpret_cast<f32x4*>(dyn_lds);             // [IPB][H][W_][C4]
   constexpr int total = 256 * W_;
   const int64_t base = (int64_t)blockIdx.x * total;
-  f32x4 ld[W_];
+  typename V4<T>::raw ld[W_];
 #pragma unroll
-  for (int j = 0; j < W_; ++j) ld[j] = in[base + threadIdx.x + 256 * j];
+  for (int j = 0; j < W_; ++j) ld[j] = in.ld(base + threadIdx.x + 256 * j);
   const int c4 = threadIdx.x % C4, y = (threadIdx.x / C4) % H, img = threadIdx.x / (C4 * H);
   f32x4 wt[9];
 #pragma unroll
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(256, 2) k_dw_fwd_img(const f32x4* __restrict__
   const f32x4 bs = bias[c4];
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int j = 0; j < W_; ++j) tile[threadIdx.x + 256 * j] = ld[j];
+  for (int j = 0; j < W_; ++j) tile[threadIdx.x + 256 * j] = V4<T>::cv(ld[j]);
   __syncthreads();
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const int ipi = H * W_ * C4;
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(256, 2) k_dw_fwd_img(const f32x4* __restrict__
 #pragma unroll
   for (int a = 0; a < 3; ++a) { win[a][1] = zero; win[a][2] = rok[a] ? rowp[a][0] : zero; }
   f32x4 gsum = zero;
-  f32x4* orow = out + base + img * ipi + y * W_ * C4 + c4;
+  const V4<T> orow = out + (base + img * ipi + y * W_ * C4 + c4);
 #pragma unroll
   for (int x = 0; x < W_; ++x) {
 #pragma unroll
@@ -179,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) k_dw_fwd_img(const f32x4* __restrict__
       for (int e = 0; e < 3; ++e) acc += wt[a * 3 + e] * win[a][e];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = acc[q] > 0.f ? acc[q] : 0.f;
-    orow[x * C4] = acc;
+    orow.st(x * C4, acc);
     gsum += acc;
   }
   // GAP: the H rows of (image, c4) through LDS (the tile is free once every thread has its outputs)
@@ -201,11 +203,11 @@ static bool dw_img_shape(int B, int H, int W, int C) {
 }
 
 // LSB = the ReLU mask (t1 > 0) arrives in the mantissa LSB of dt2 (written by k_gemm_dual's conv2 pair): t1 is not read
-template <bool LSB>
-__global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ dt2, const f32x4* __restrict__ t1,
-                                                     const f32x4* __restrict__ t0, const f32x4* __restrict__ w,
+template <bool LSB, typename ST>
+__global__ void __launch_bounds__(256) k_dw_bwd_ring(const V4<ST> dt2, const V4<ST> t1,
+                                                     const V4<ST> t0, const f32x4* __restrict__ w,
                                                      const f32x4* __restrict__ gate, const f32x4* __restrict__ dgap,
-                                                     f32x4* __restrict__ dt0, float* __restrict__ dW,
+                                                     const V4<ST> dt0, float* __restrict__ dW,
                                                      float* __restrict__ db, DwGeom g, float inv_hw, int B, int RS,
                                                      int nseg, int nslots, int64_t slot_stride) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
@@ -233,41 +235,45 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
     // LDS store.  t0 rows ride a second two-slot FIFO.  The row loop is unrolled by two (static slots) and is
     // straight-line code (clamped addresses, RS even): the compiler then waits with exact vmcnt(N) counts and the
     // loads of the next two rows stay in flight under the current row's arithmetic.
-    f32x4 Fd[2][3], Fa[2][3], T[2][2];
+    typedef typename V4<ST>::raw raw_t;
+    raw_t Fd[2][3], Fa[2][3], T[2][2];
     const f32x4 gg_c = gate[(int64_t)b * g.C4 + c4];       // (row_items % C4 == 0 and 256 % C4 == 0: cc == c4)
     const f32x4 dg_c = dgap[(int64_t)b * g.C4 + c4] * inv_hw;
     const int ybc = min(yb, g.H - 1);                      // last d1 row this item needs
-    auto fetch_row = [&](int y, f32x4 (&rd)[3], f32x4 (&ra)[3]) {
+    auto fetch_row = [&](int y, raw_t (&rd)[3], raw_t (&ra)[3]) {
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int t = threadIdx.x + 256 * u;
         const int x = x0 - 1 + t / g.C4;
         const bool ok = t < row_items && x >= 0 && x < g.W;
         const int64_t o = ok ? ioff + ((int64_t)y * g.W + x) * g.C4 + c4 : 0;
-        rd[u] = dt2[o];
-        if constexpr (!LSB) ra[u] = t1[o];
+        rd[u] = dt2.ld(o);
+        if constexpr (!LSB) ra[u] = t1.ld(o);
       }
     };
-    auto store_row = [&](int y, const f32x4 (&rd)[3], const f32x4 (&ra)[3]) {   // d1 row y (+ halo) -> ring slot y & 3
+    auto store_row = [&](int y, const raw_t (&rdr)[3], const raw_t (&rar)[3]) {   // d1 row y (+ halo) -> ring slot y & 3
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int t = threadIdx.x + 256 * u;
         const int x = x0 - 1 + t / g.C4;
         const bool ok = x >= 0 && x < g.W;
         if (t < row_items) {
+          const f32x4 rd = V4<ST>::cv(rdr[u]);
+          f32x4 ra = rd;
+          if constexpr (!LSB) ra = V4<ST>::cv(rar[u]);
           f32x4 v;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const bool on = LSB ? (__float_as_uint(rd[u][q]) & 1u) != 0u : ra[u][q] > 0.f;
-            v[q] = (ok && on) ? rd[u][q] * gg_c[q] + dg_c[q] : 0.f;
+            const bool on = LSB ? (__float_as_uint(rd[q]) & 1u) != 0u : ra[q] > 0.f;
+            v[q] = (ok && on) ? rd[q] * gg_c[q] + dg_c[q] : 0.f;
           }
           RING(y & 3, t / g.C4, c4) = v;
         }
       }
     };
-    auto fetch_t0 = [&](int y, f32x4 (&tv)[2]) {
-      tv[0] = t0[has0 ? ioff + ((int64_t)y * g.W + x0 + xl0) * g.C4 + c4 : 0];
-      tv[1] = t0[has1 ? ioff + ((int64_t)y * g.W + x0 + xl1) * g.C4 + c4 : 0];
+    auto fetch_t0 = [&](int y, raw_t (&tv)[2]) {
+      tv[0] = t0.ld(has0 ? ioff + ((int64_t)y * g.W + x0 + xl0) * g.C4 + c4 : 0);
+      tv[1] = t0.ld(has1 ? ioff + ((int64_t)y * g.W + x0 + xl1) * g.C4 + c4 : 0);
     };
     __syncthreads();                                  // previous item's ring reads are done
     // prologue: d1 rows ya-1 (for ya = 0: a copy of row 0 in a slot nobody reads) and ya go to the ring at once
@@ -290,7 +296,7 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
         for (int k = 0; k < 2; ++k) {
           const bool has = k == 0 ? has0 : has1;
           const int xl = k == 0 ? xl0 : xl1;
-          const f32x4 tvk = has ? T[kk][k] : f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 tvk = has ? V4<ST>::cv(T[kk][k]) : f32x4{0.f, 0.f, 0.f, 0.f};
           if (has) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             // position (y,x) was read by output pixel (y-a+1, x-e+1) through tap (a,e)
@@ -309,7 +315,7 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
             f32x4 r;
 #pragma unroll
             for (int q = 0; q < 4; ++q) r[q] = tvk[q] > 0.f ? acc[q] : 0.f;
-            dt0[ioff + ((int64_t)y * g.W + x0 + xl) * g.C4 + c4] = r;
+            dt0.st(ioff + ((int64_t)y * g.W + x0 + xl) * g.C4 + c4, r);
           }
         }
         fetch_t0(min(y + 2, yb - 1), T[kk]);
@@ -348,10 +354,10 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const f32x4* __restrict__ d
 // the row with a 3x3 window of d1 = (dt2 * gate + dgap / hw) * mask, formed as the window is filled.
 // XS = 2: two threads share an output row (half of it each), 512 threads per block -- the 16-wide x 64-channel case, where
 // one thread per row needs more than 256 registers
-template <int W_, int C4, int XS>
-__global__ void __launch_bounds__(256 * XS, XS == 2 ? 1 : 2) k_dw_bwd_img(const f32x4* __restrict__ dt2, const f32x4* __restrict__ t0,
+template <int W_, int C4, int XS, typename T>
+__global__ void __launch_bounds__(256 * XS, XS == 2 ? 1 : 2) k_dw_bwd_img(const V4<T> dt2, const V4<T> t0,
                                                        const f32x4* __restrict__ w, const f32x4* __restrict__ gate,
-                                                       const f32x4* __restrict__ dgap, f32x4* __restrict__ dt0,
+                                                       const f32x4* __restrict__ dgap, const V4<T> dt0,
                                                        float* __restrict__ dW, float* __restrict__ db, int H,
                                                        float inv_hw, int nslots, int64_t slot_stride) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
@@ -364,12 +370,12 @@ __global__ void __launch_bounds__(256 * XS, XS == 2 ? 1 : 2) k_dw_bwd_img(const 
   // the t0 row rides a 4-deep register FIFO (fetched four steps ahead of its use): the whole row next to the 19 float4
   // accumulators and the window does not fit 256 registers
   constexpr int FD = XL < 4 ? XL : 4;
-  f32x4 ld[XL], t0q[FD];
+  typename V4<T>::raw ld[XL], t0q[FD];
 #pragma unroll
-  for (int j = 0; j < XL; ++j) ld[j] = dt2[base + threadIdx.x + NTHR * j];
-  const f32x4* t0p = t0 + base + img * ipi + (y * W_ + x0) * C4 + c4;
+  for (int j = 0; j < XL; ++j) ld[j] = dt2.ld(base + threadIdx.x + NTHR * j);
+  const V4<T> t0p = t0 + (base + img * ipi + (y * W_ + x0) * C4 + c4);
 #pragma unroll
-  for (int x = 0; x < FD; ++x) t0q[x] = t0p[x * C4];
+  for (int x = 0; x < FD; ++x) t0q[x] = t0p.ld(x * C4);
   const int64_t bimg = (int64_t)blockIdx.x * ipb + img;
   const f32x4 gg = gate[bimg * C4 + c4];
   const f32x4 dg = dgap[bimg * C4 + c4] * inv_hw;
@@ -378,7 +384,7 @@ __global__ void __launch_bounds__(256 * XS, XS == 2 ? 1 : 2) k_dw_bwd_img(const 
   for (int k = 0; k < 9; ++k) wt[k] = w[k * C4 + c4];
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int j = 0; j < XL; ++j) tile[threadIdx.x + NTHR * j] = ld[j];
+  for (int j = 0; j < XL; ++j) tile[threadIdx.x + NTHR * j] = V4<T>::cv(ld[j]);
   __syncthreads();
   f32x4 aw[9];
 #pragma unroll
@@ -414,7 +420,7 @@ __global__ void __launch_bounds__(256 * XS, XS == 2 ? 1 : 2) k_dw_bwd_img(const 
     win[a][1] = left ? l : zero;
     win[a][0] = d1_at(a, 0);
   }
-  f32x4* orow = dt0 + base + img * ipi + (y * W_ + x0) * C4 + c4;
+  const V4<T> orow = dt0 + (base + img * ipi + (y * W_ + x0) * C4 + c4);
 #pragma unroll
   for (int x = 0; x < XL; ++x) {
 #pragma unroll
@@ -424,8 +430,8 @@ __global__ void __launch_bounds__(256 * XS, XS == 2 ? 1 : 2) k_dw_bwd_img(const 
       else if (XS == 1) win[a][0] = zero;
       else { const f32x4 r = d1_at(a, right ? XL : XL - 1); win[a][0] = right ? r : zero; }
     }
-    const f32x4 tv = t0q[x % FD];
-    if (x + FD < XL) t0q[x % FD] = t0p[(x + FD) * C4];
+    const f32x4 tv = V4<T>::cv(t0q[x % FD]);
+    if (x + FD < XL) t0q[x % FD] = t0p.ld((x + FD) * C4);
     f32x4 acc = zero;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -438,7 +444,7 @@ __global__ void __launch_bounds__(256 * XS, XS == 2 ? 1 : 2) k_dw_bwd_img(const 
     f32x4 r;
 #pragma unroll
     for (int q = 0; q < 4; ++q) r[q] = tv[q] > 0.f ? acc[q] : 0.f;
-    orow[x * C4] = r;
+    orow.st(x * C4, r);
     __builtin_amdgcn_sched_barrier(0);                 // keeps the scheduler from hoisting every later window read up here
   }
   // ---- block reduction of the 10 float4 accumulators over the threads that share c4, one atomic set per block
@@ -484,8 +490,9 @@ bool dw_uses_img(bool backward, bool mask_in_lsb, int B, int H, int W, int C) {
 }
 
 // t1 = relu(dw(t0) + b) and gap = mean_hw(t1) in one pass.  false = shape not covered.
-bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* out, float* gap, int B, int H, int W,
-                       int C, hipStream_t s) {
+template <typename T>
+static bool run_dw_fwd_gap(const T* in, const float* w, const float* b, T* out, float* gap, int B, int H, int W, int C,
+                           hipStream_t s) {
   if (dw_uses_img(false, false, B, H, W, C)) {
     const int ipb = 256 / (H * (C / 4));
     const dim3 grid((unsigned)(B / ipb));
@@ -493,10 +500,10 @@ bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* o
     const float inv = 1.0f / (float)(H * W);
 #define MVAE_DWI(W_)                                                                                                  \
   do {                                                                                                                \
-    if (C == 64) hipLaunchKernelGGL((k_dw_fwd_img<W_, 16>), grid, dim3(256), bytes, s, (const f32x4*)in,             \
-                                    (const f32x4*)w, (const f32x4*)b, (f32x4*)out, gap, H, inv);                     \
-    else hipLaunchKernelGGL((k_dw_fwd_img<W_, 8>), grid, dim3(256), bytes, s, (const f32x4*)in, (const f32x4*)w,     \
-                            (const f32x4*)b, (f32x4*)out, gap, H, inv);                                              \
+    if (C == 64) hipLaunchKernelGGL((k_dw_fwd_img<W_, 16, T>), grid, dim3(256), bytes, s, V4<T>(in),                 \
+                                    (const f32x4*)w, (const f32x4*)b, V4<T>(out), gap, H, inv);                      \
+    else hipLaunchKernelGGL((k_dw_fwd_img<W_, 8, T>), grid, dim3(256), bytes, s, V4<T>(in), (const f32x4*)w,         \
+                            (const f32x4*)b, V4<T>(out), gap, H, inv);                                               \
   } while (0)
     if (W == 16) MVAE_DWI(16); else if (W == 8) MVAE_DWI(8); else MVAE_DWI(4);
 #undef MVAE_DWI
@@ -506,16 +513,21 @@ bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* o
   size_t lds;
   if (!dw_geom(H, W, C, &g, &lds) || B > 65535 || (H % 4) != 0) return false;
   if (g.strips > 1) launch_zero(gap, (int64_t)B * C, s);
-  hipLaunchKernelGGL(k_dw_fwd_ring<true>, dim3(g.strips, B), dim3(256), lds, s, (const f32x4*)in, (const f32x4*)w,
-                     (const f32x4*)b, (f32x4*)out, gap, g, 1.0f / (float)(H * W));
+  hipLaunchKernelGGL((k_dw_fwd_ring<true, T>), dim3(g.strips, B), dim3(256), lds, s, V4<T>(in), (const f32x4*)w,
+                     (const f32x4*)b, V4<T>(out), gap, g, 1.0f / (float)(H * W));
   return true;
+}
+bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* out, float* gap, int B, int H, int W,
+                       int C, hipStream_t s, bool bf) {
+  if (bf) return run_dw_fwd_gap<bf16_t>((const bf16_t*)in, w, b, (bf16_t*)out, gap, B, H, W, C, s);
+  return run_dw_fwd_gap<float>(in, w, b, out, gap, B, H, W, C, s);
 }
 
 // fused backward through Multiply/GAP/ReLU + depthwise backward-data + depthwise weight/bias gradients.
-// `partial` is a scratch buffer of kDwMaxBlocks * 10 * C floats.
-bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
-                         const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
-                         int W, int C, hipStream_t s) {
+template <typename T>
+static bool run_dw_bwd_fused(const T* dt2, const T* t1, const T* t0, const float* w, const float* gate,
+                             const float* dgap, T* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
+                             int W, int C, hipStream_t s) {
   if (dw_uses_img(true, mask_in_lsb, B, H, W, C)) {
     const int ipb = 256 / (H * (C / 4));
     const dim3 grid((unsigned)(B / ipb));
@@ -524,11 +536,11 @@ bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, con
 #define MVAE_DWB(W_)                                                                                                  \
   do {                                                                                                                \
     constexpr int XS = W_ == 16 ? 2 : 1;                    /* 16-wide rows: two threads per row, 512 per block */    \
-    if (C == 64) hipLaunchKernelGGL((k_dw_bwd_img<W_, 16, XS>), grid, dim3(256 * XS), bytes, s, (const f32x4*)dt2,   \
-                                    (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap,       \
-                                    (f32x4*)dt0, sl.at(dW), sl.at(db), H, inv, sl.count(), sl.stride);               \
-    else hipLaunchKernelGGL((k_dw_bwd_img<W_, 8, XS>), grid, dim3(256 * XS), bytes, s, (const f32x4*)dt2,            \
-                            (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0,  \
+    if (C == 64) hipLaunchKernelGGL((k_dw_bwd_img<W_, 16, XS, T>), grid, dim3(256 * XS), bytes, s, V4<T>(dt2),       \
+                                    V4<T>(t0), (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap,              \
+                                    V4<T>(dt0), sl.at(dW), sl.at(db), H, inv, sl.count(), sl.stride);                \
+    else hipLaunchKernelGGL((k_dw_bwd_img<W_, 8, XS, T>), grid, dim3(256 * XS), bytes, s, V4<T>(dt2),                \
+                            V4<T>(t0), (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, V4<T>(dt0),          \
                             sl.at(dW), sl.at(db), H, inv, sl.count(), sl.stride);                                    \
   } while (0)
     if (W == 16) MVAE_DWB(16); else if (W == 8) MVAE_DWB(8); else MVAE_DWB(4);
@@ -551,14 +563,23 @@ bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, con
   int gy = (int)(work < kDwMaxBlocks / g.strips ? work : kDwMaxBlocks / g.strips);
   if (gy < 1) return false;
   if (mask_in_lsb)
-    hipLaunchKernelGGL(k_dw_bwd_ring<true>, dim3(g.strips, gy), dim3(256), lds, s, (const f32x4*)dt2, (const f32x4*)t1,
-                       (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0, sl.at(dW),
+    hipLaunchKernelGGL((k_dw_bwd_ring<true, T>), dim3(g.strips, gy), dim3(256), lds, s, V4<T>(dt2), V4<T>(t1),
+                       V4<T>(t0), (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, V4<T>(dt0), sl.at(dW),
                        sl.at(db), g, 1.0f / (float)(H * W), B, RS, nseg, sl.count(), sl.stride);
   else
-    hipLaunchKernelGGL(k_dw_bwd_ring<false>, dim3(g.strips, gy), dim3(256), lds, s, (const f32x4*)dt2, (const f32x4*)t1,
-                       (const f32x4*)t0, (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, (f32x4*)dt0, sl.at(dW),
+    hipLaunchKernelGGL((k_dw_bwd_ring<false, T>), dim3(g.strips, gy), dim3(256), lds, s, V4<T>(dt2), V4<T>(t1),
+                       V4<T>(t0), (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, V4<T>(dt0), sl.at(dW),
                        sl.at(db), g, 1.0f / (float)(H * W), B, RS, nseg, sl.count(), sl.stride);
   return true;
+}
+// bf: bfloat16 storage (the ReLU mask then comes from t1: mask_in_lsb must be false)
+bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
+                         const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
+                         int W, int C, hipStream_t s, bool bf) {
+  if (bf)
+    return !mask_in_lsb && run_dw_bwd_fused<bf16_t>((const bf16_t*)dt2, (const bf16_t*)t1, (const bf16_t*)t0, w, gate, dgap,
+                                                    (bf16_t*)dt0, dW, db, sl, false, B, H, W, C, s);
+  return run_dw_bwd_fused<float>(dt2, t1, t0, w, gate, dgap, dt0, dW, db, sl, mask_in_lsb, B, H, W, C, s);
 }
 
 }  // namespace mvae

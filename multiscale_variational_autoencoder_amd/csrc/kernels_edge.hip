@@ -6,6 +6,7 @@
 //   * decoder head: BatchNormalization(0.999, 1e-4) -> Conv2D(1x1, 32->C) (multiscale_vae.py:420-431): the
 //     forward folds BN into the conv read; the backward is ONE reduction pass (BN sums, dW, db) and ONE apply pass.
 #include "kernels.h"
+#include "act16.h"
 
 namespace mvae {
 
@@ -121,9 +122,9 @@ __device__ __forceinline__ float elu_neg(float v) {
 // two patch elements per v_mfma_f32_32x32x2_f32 (lane half h takes element 2s + h).  A wave owns 32 consecutive
 // pixels; W (one column per lane) stays in registers; the patch loads are raw + clamped, issued ahead of the MFMAs;
 // D leaves straight from the accumulator layout (each store instruction = two whole 128-byte pixels) after bias + ELU.
-template <int CI>
+template <int CI, typename T>
 __global__ void __launch_bounds__(256) k_convbase_fwd_mfma(const float* __restrict__ in, const float* __restrict__ W,
-                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           const float* __restrict__ bias, T* __restrict__ out,
                                                            int B, int H, int Wd, int ntiles) {
   constexpr int KP = 9 * CI, NS = (KP + 1) / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -167,13 +168,13 @@ __global__ void __launch_bounds__(256) k_convbase_fwd_mfma(const float* __restri
     for (int st = 0; st < NS; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st] * am[st], wreg[st], acc, 0, 0, 0);
     const int64_t left = (int64_t)M - (int64_t)tile * 32 - 4 * h;
     const int lim = left < 32 ? (int)left : 32;
-    float* po = out + ((int64_t)tile * 32 + 4 * h) * 32 + i;
+    T* po = out + ((int64_t)tile * 32 + 4 * h) * 32 + i;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rc = (r & 3) + 8 * (r >> 2);
       float v = acc[r] + bz;
       v = v > 0.f ? v : elu_neg(v);
-      if (rc < lim) po[rc * 32] = v;
+      if (rc < lim) st1(po, rc * 32, v);
     }
   }
 }
@@ -181,8 +182,9 @@ __global__ void __launch_bounds__(256) k_convbase_fwd_mfma(const float* __restri
 // MFMA form of the conv_base weight gradient for 9*CI <= 32 (C <= 3): the [27 x 32] gradient is ONE 32x32 tile,
 // D[i = patch element k][j = co] += patch[m][k] * dpre[m][co], two pixels m per v_mfma_f32_32x32x2_f32.
 // A wave walks whole image rows; lane i decodes its patch element (a, e, ci) once.  4 waves reduce through LDS.
-__global__ void __launch_bounds__(256) k_convbase_wgrad_mfma(const float* __restrict__ in, const float* __restrict__ dy,
-                                                             const float* __restrict__ y, float* __restrict__ dW,
+template <typename T>
+__global__ void __launch_bounds__(256) k_convbase_wgrad_mfma(const float* __restrict__ in, const T* __restrict__ dy,
+                                                             const T* __restrict__ y, float* __restrict__ dW,
                                                              float* __restrict__ db, int B, int H, int Wd, int CI,
                                                              int rows_per_wave, int nslots, int64_t slot_stride) {
   __shared__ float red[4][16][64];
@@ -204,8 +206,8 @@ __global__ void __launch_bounds__(256) k_convbase_wgrad_mfma(const float* __rest
     const int yy = yy0 + a - 1;
     const bool yok = kv && yy >= 0 && yy < H;
     const float* irow = in + ((b * H + (yok ? yy : 0)) * Wd) * CI + ci;
-    const float* drow = dy + rr * Wd * 32 + i;
-    const float* yrow = y + rr * Wd * 32 + i;
+    const T* drow = dy + rr * Wd * 32 + i;
+    const T* yrow = y + rr * Wd * 32 + i;
     for (int x = 0; x < Wd; x += 8) {             // 4 pixel pairs per trip: 12 raw (clamped) loads, then the MFMAs
       float av[4], dv[4], yv[4], am[4], dm[4];
 #pragma unroll
@@ -218,8 +220,8 @@ __global__ void __launch_bounds__(256) k_convbase_wgrad_mfma(const float* __rest
         dm[u] = mv ? 1.f : 0.f;
         av[u] = irow[(aok ? xx : 0) * CI];
         const int xc = mv ? xm : 0;
-        yv[u] = yrow[xc * 32];
-        dv[u] = drow[xc * 32];
+        yv[u] = ld1(yrow, xc * 32);
+        dv[u] = ld1(drow, xc * 32);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -250,7 +252,8 @@ __global__ void __launch_bounds__(256) k_convbase_wgrad_mfma(const float* __rest
 // decoder head.  DC4 = dc/4 lanes per pixel (dc = BatchNorm channels, a power of two >= 4), C <= 8 outputs.
 // forward: y[m,o] = b[o] + sum_c (x[m,c] * scale[c] + shift[c]) * W[c][o]
 // -------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_head_fwd(const f32x4* __restrict__ x, const float* __restrict__ scale,
+template <typename T>
+__global__ void __launch_bounds__(256) k_head_fwd(const V4<T> x, const float* __restrict__ scale,
                                                   const float* __restrict__ shift, const float* __restrict__ W,
                                                   const float* __restrict__ bias, float* __restrict__ yout, int64_t M,
                                                   int dc4, int C) {
@@ -286,8 +289,8 @@ __global__ void __launch_bounds__(256) k_head_fwd(const f32x4* __restrict__ x, c
 // with wave shuffles, over the 4 waves through LDS, and leave as ONE atomic set per block into slot (block % nslots):
 // S = [nslots][2][dc] (summed by the apply pass), dW/db through the gradient slots (kernels.h: GradSlots).
 constexpr int kHeadSlots = 16;
-template <int C>
-__global__ void __launch_bounds__(256) k_head_bwd_reduce(const f32x4* __restrict__ x, const float* __restrict__ dy,
+template <int C, typename T>
+__global__ void __launch_bounds__(256) k_head_bwd_reduce(const V4<T> x, const float* __restrict__ dy,
                                                          const float* __restrict__ W, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ mean,
@@ -312,6 +315,7 @@ __global__ void __launch_bounds__(256) k_head_bwd_reduce(const f32x4* __restrict
   int64_t p1 = p0 + ppb;
   if (p1 > M) p1 = M;
   for (int64_t pb = p0 + pl; pb < p1; pb += 4 * npl) {
+    typename V4<T>::raw xr[4];
     f32x4 xv[4];
     float d[4][C], msk[4];
 #pragma unroll
@@ -320,13 +324,14 @@ __global__ void __launch_bounds__(256) k_head_bwd_reduce(const f32x4* __restrict
       const bool ok = p < p1;
       const int64_t pc = ok ? p : p0;
       msk[u] = ok ? 1.f : 0.f;
-      xv[u] = x[pc * dc4 + c4];
+      xr[u] = x.ld(pc * dc4 + c4);
 #pragma unroll
       for (int o = 0; o < C; ++o) d[u][o] = dy[pc * C + o];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      xv[u] = V4<T>::cv(xr[u]);
 #pragma unroll
       for (int o = 0; o < C; ++o) d[u][o] *= msk[u];
 #pragma unroll
@@ -369,12 +374,12 @@ __global__ void __launch_bounds__(256) k_head_bwd_reduce(const f32x4* __restrict
 
 // backward pass 2 (apply): d[m,c] = gamma*invstd * (dxbn - S1/M - xhat * S2/M); block 0 also adds the BatchNorm
 // parameter gradients dgamma += S2, dbeta += S1
-template <int C>
-__global__ void __launch_bounds__(256) k_head_bwd_apply(const f32x4* __restrict__ x, const float* __restrict__ dy,
+template <int C, typename T>
+__global__ void __launch_bounds__(256) k_head_bwd_apply(const V4<T> x, const float* __restrict__ dy,
                                                         const float* __restrict__ W, const float* __restrict__ gamma,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ S,
-                                                        f32x4* __restrict__ dout, float* __restrict__ dgamma,
+                                                        const V4<T> dout, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int64_t M, int dc4, int nslots) {
   const int c4 = threadIdx.x % dc4, pl = threadIdx.x / dc4, ppb = 256 / dc4;
   const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
@@ -400,19 +405,21 @@ __global__ void __launch_bounds__(256) k_head_bwd_apply(const f32x4* __restrict_
     for (int o = 0; o < C; ++o) w[e][o] = W[(c4 * 4 + e) * C + o];
   const int64_t stride = (int64_t)gridDim.x * ppb;
   for (int64_t pb = (int64_t)blockIdx.x * ppb + pl; pb < M; pb += 4 * stride) {
+    typename V4<T>::raw xr[4];
     f32x4 xv[4];
     float d[4][C];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t p = pb + u * stride;
       const int64_t pc = p < M ? p : pb;
-      xv[u] = x[pc * dc4 + c4];
+      xr[u] = x.ld(pc * dc4 + c4);
 #pragma unroll
       for (int o = 0; o < C; ++o) d[u][o] = dy[pc * C + o];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      xv[u] = V4<T>::cv(xr[u]);
       f32x4 r;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -423,7 +430,7 @@ __global__ void __launch_bounds__(256) k_head_bwd_apply(const f32x4* __restrict_
         r[e] = gm[e] * is[e] * (dx - m1[e] - xh * m2[e]);
       }
       const int64_t p = pb + u * stride;
-      if (p < M) dout[p * dc4 + c4] = r;
+      if (p < M) dout.st(p * dc4 + c4, r);
     }
   }
 }
@@ -431,32 +438,46 @@ __global__ void __launch_bounds__(256) k_head_bwd_apply(const f32x4* __restrict_
 // ---- launchers (false = shape not covered, caller uses the generic kernels) -----------------------------------
 static inline int cap_grid(int64_t g) { return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g)); }
 
-bool launch_convbase_fwd(const float* in, const float* W, const float* bias, float* out, int B, int H, int Wd, int CI,
-                         int CO, hipStream_t s) {
+template <typename T>
+static bool run_convbase_fwd(const float* in, const float* W, const float* bias, T* out, int B, int H, int Wd, int CI,
+                             int CO, hipStream_t s) {
   if (CO != 32 || CI > 4) return false;
   int64_t M = (int64_t)B * H * Wd;
   if (M < (1ll << 31) - 64 && (CI == 3 || CI == 1)) {
     const int ntiles = (int)((M + 31) / 32);
     const int grid = cap_grid((ntiles + 3) / 4);
-    if (CI == 3) hipLaunchKernelGGL(k_convbase_fwd_mfma<3>, dim3(grid), dim3(256), 0, s, in, W, bias, out, B, H, Wd, ntiles);
-    else hipLaunchKernelGGL(k_convbase_fwd_mfma<1>, dim3(grid), dim3(256), 0, s, in, W, bias, out, B, H, Wd, ntiles);
+    if (CI == 3) hipLaunchKernelGGL((k_convbase_fwd_mfma<3, T>), dim3(grid), dim3(256), 0, s, in, W, bias, out, B, H, Wd, ntiles);
+    else hipLaunchKernelGGL((k_convbase_fwd_mfma<1, T>), dim3(grid), dim3(256), 0, s, in, W, bias, out, B, H, Wd, ntiles);
     return true;
   }
+  return false;
+}
+bool launch_convbase_fwd(const float* in, const float* W, const float* bias, float* out, int B, int H, int Wd, int CI,
+                         int CO, hipStream_t s, bool bf) {
+  if (bf) return run_convbase_fwd<bf16_t>(in, W, bias, (bf16_t*)out, B, H, Wd, CI, CO, s);
+  if (run_convbase_fwd<float>(in, W, bias, out, B, H, Wd, CI, CO, s)) return true;
+  if (CO != 32 || CI > 4) return false;
+  int64_t M = (int64_t)B * H * Wd;
   hipLaunchKernelGGL(k_convbase_fwd, dim3(cap_grid((M + 31) / 32)), dim3(256), 0, s, in, W, bias, out, B, H, Wd, CI);
   return true;
 }
 bool launch_convbase_wgrad(const float* in, const float* dy, const float* y, float* dW, float* db, int B, int H, int Wd,
-                           int CI, int CO, GradSlots sl, hipStream_t s) {
+                           int CI, int CO, GradSlots sl, hipStream_t s, bool bf) {
   if (CO != 32 || CI > 4) return false;
   if (9 * CI <= 32) {
     const int64_t nrows = (int64_t)B * H;
     int rpw = 1;
     while (nrows / rpw > 4096) rpw *= 2;            // <= 4096 waves: bounds the float-atomic traffic
     const int64_t waves = (nrows + rpw - 1) / rpw;
-    hipLaunchKernelGGL(k_convbase_wgrad_mfma, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in, dy, y, sl.at(dW),
-                       sl.at(db), B, H, Wd, CI, rpw, sl.count(), sl.stride);
+    if (bf)
+      hipLaunchKernelGGL(k_convbase_wgrad_mfma<bf16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in,
+                         (const bf16_t*)dy, (const bf16_t*)y, sl.at(dW), sl.at(db), B, H, Wd, CI, rpw, sl.count(), sl.stride);
+    else
+      hipLaunchKernelGGL(k_convbase_wgrad_mfma<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in, dy, y, sl.at(dW),
+                         sl.at(db), B, H, Wd, CI, rpw, sl.count(), sl.stride);
     return true;
   }
+  if (bf) return false;
   int64_t M = (int64_t)B * H * Wd;
   int64_t ppb = 512;
   while ((M + ppb - 1) / ppb > 1024) ppb *= 2;
@@ -469,37 +490,50 @@ static bool head_ok(int dc, int C) {
   return true;
 }
 bool launch_head_fwd(const float* x, const float* scale, const float* shift, const float* W, const float* bias,
-                     float* y, int64_t M, int dc, int C, hipStream_t s) {
+                     float* y, int64_t M, int dc, int C, hipStream_t s, bool bf) {
   if (!head_ok(dc, C)) return false;
   const int dc4 = dc / 4, ppb = 256 / dc4;
-  hipLaunchKernelGGL(k_head_fwd, dim3(cap_grid((M + ppb - 1) / ppb)), dim3(256), 0, s, (const f32x4*)x, scale, shift, W,
-                     bias, y, M, dc4, C);
+  if (bf)
+    hipLaunchKernelGGL(k_head_fwd<bf16_t>, dim3(cap_grid((M + ppb - 1) / ppb)), dim3(256), 0, s, V4<bf16_t>((const bf16_t*)x),
+                       scale, shift, W, bias, y, M, dc4, C);
+  else
+    hipLaunchKernelGGL(k_head_fwd<float>, dim3(cap_grid((M + ppb - 1) / ppb)), dim3(256), 0, s, V4<float>(x), scale, shift, W,
+                       bias, y, M, dc4, C);
   return true;
 }
 int head_slots() { return kHeadSlots; }
-template <int C>
-static void run_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,
+template <int C, typename T>
+static void run_head_bwd(const T* x, const float* dy, const float* W, const float* gamma, const float* scale,
                          const float* shift, const float* mean, const float* invstd, float* S, float* dW, float* db,
-                         float* dgamma, float* dbeta, float* dout, int64_t M, int dc, GradSlots sl, hipStream_t s) {
+                         float* dgamma, float* dbeta, T* dout, int64_t M, int dc, GradSlots sl, hipStream_t s) {
   const int dc4 = dc / 4, npl = 256 / dc4;
   int64_t ppb = 16 * npl;                                  // >= 16 pixels per thread
   while ((M + ppb - 1) / ppb > 2048) ppb *= 2;
-  hipLaunchKernelGGL(k_head_bwd_reduce<C>, dim3((unsigned)((M + ppb - 1) / ppb)), dim3(256), 0, s, (const f32x4*)x, dy, W,
+  hipLaunchKernelGGL((k_head_bwd_reduce<C, T>), dim3((unsigned)((M + ppb - 1) / ppb)), dim3(256), 0, s, V4<T>(x), dy, W,
                      scale, shift, mean, invstd, S, sl.at(dW), sl.at(db), M, dc4, ppb, sl.count(), sl.stride);
-  hipLaunchKernelGGL(k_head_bwd_apply<C>, dim3(cap_grid((M + 4 * npl - 1) / (4 * npl))), dim3(256), 0, s,
-                     (const f32x4*)x, dy, W, gamma, mean, invstd, S, (f32x4*)dout, dgamma, dbeta, M, dc4, kHeadSlots);
+  hipLaunchKernelGGL((k_head_bwd_apply<C, T>), dim3(cap_grid((M + 4 * npl - 1) / (4 * npl))), dim3(256), 0, s,
+                     V4<T>(x), dy, W, gamma, mean, invstd, S, V4<T>(dout), dgamma, dbeta, M, dc4, kHeadSlots);
+}
+template <typename T>
+static bool run_head_bwd_c(const T* x, const float* dy, const float* W, const float* gamma, const float* scale,
+                           const float* shift, const float* mean, const float* invstd, float* S, float* dW, float* db,
+                           float* dgamma, float* dbeta, T* dout, int64_t M, int dc, int C, GradSlots sl, hipStream_t s) {
+  if (C == 3) run_head_bwd<3, T>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
+  else if (C == 1) run_head_bwd<1, T>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
+  else if (C == 4) run_head_bwd<4, T>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
+  else return false;
+  return true;
 }
 // S: [head_slots()][2][dc] floats, zeroed by the caller.  Adds dW, db (through the gradient slots), dgamma, dbeta.
 bool launch_head_bwd(const float* x, const float* dy, const float* W, const float* gamma, const float* scale,
                      const float* shift, const float* mean, const float* invstd, float* S, float* dW, float* db,
-                     float* dgamma, float* dbeta, float* dout, int64_t M, int dc, int C, GradSlots sl, hipStream_t s) {
+                     float* dgamma, float* dbeta, float* dout, int64_t M, int dc, int C, GradSlots sl, hipStream_t s, bool bf) {
   if (!head_ok(dc, C)) return false;
   // the reduce pass folds S into slot (block % kHeadSlots) and dW/db into gradient slot (block % sl.count())
-  if (C == 3) run_head_bwd<3>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
-  else if (C == 1) run_head_bwd<1>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
-  else if (C == 4) run_head_bwd<4>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
-  else return false;
-  return true;
+  if (bf)
+    return run_head_bwd_c<bf16_t>((const bf16_t*)x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta,
+                                  (bf16_t*)dout, M, dc, C, sl, s);
+  return run_head_bwd_c<float>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, C, sl, s);
 }
 
 }  // namespace mvae

@@ -4,6 +4,7 @@
 // window).  Reference: mvae/multiscale_vae.py:358-370,402-406 (Dense mu / log_var / decoder Dense),
 // mvae/layer_blocks.py:440-456 (SE Dense), :604-614 (DepthwiseConv2D).
 #include "kernels.h"
+#include "act16.h"
 #include "prof.h"
 
 namespace mvae {
@@ -354,8 +355,8 @@ bool launch_dw_wgrad_opt(const float* in, const float* dy, float* dW, float* db,
 // mean[c] = inv_m * sum over the `msl` slot copies of a MODE 0 result.  The block's result leaves as one atomic set into
 // slot (block % nslots) (kernels.h: GradSlots -- a few hundred blocks adding into ONE 128-byte line serialise).
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ void __launch_bounds__(256) k_colstat4(const f32x4* __restrict__ x, const float* __restrict__ msum, int msl,
+template <int MODE, typename T>
+__global__ void __launch_bounds__(256) k_colstat4(const V4<T> x, const float* __restrict__ msum, int msl,
                                                   float inv_m, float* __restrict__ out, int nslots, int64_t slot_stride,
                                                   int64_t M, int C4, int64_t rpb) {
   __shared__ f32x4 red[4][64];
@@ -371,21 +372,22 @@ __global__ void __launch_bounds__(256) k_colstat4(const f32x4* __restrict__ x, c
   if (m1 > M) m1 = M;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int64_t mb = m0 + rl; mb < m1; mb += 8 * nr) {
-    f32x4 v[8];
+    typename V4<T>::raw vr[8];
     float mk[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int64_t m = mb + u * nr;
       mk[u] = m < m1 ? 1.f : 0.f;
-      v[u] = x[(m < m1 ? m : m0) * C4 + c4];
+      vr[u] = x.ld((m < m1 ? m : m0) * C4 + c4);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
+      const f32x4 v = V4<T>::cv(vr[u]);
       if (MODE == 0) {
-        acc += v[u] * mk[u];
+        acc += v * mk[u];
       } else {
-        const f32x4 d = v[u] - mean;
+        const f32x4 d = v - mean;
         acc += d * d * mk[u];
       }
     }
@@ -405,19 +407,23 @@ __global__ void __launch_bounds__(256) k_colstat4(const f32x4* __restrict__ x, c
 
 // false = shape not covered (C not a power-of-two multiple of 4 up to 256)
 bool launch_colstat_opt(int mode, const float* x, const float* msum, int msl, float inv_m, float* out, int nslots,
-                        int64_t slot_stride, int64_t M, int C, hipStream_t s) {
+                        int64_t slot_stride, int64_t M, int C, hipStream_t s, bool bf) {
   if (C < 4 || C > 256 || (C & (C - 1))) return false;
   const int C4 = C / 4, nr = 256 / C4;
   int64_t rpb = 8 * nr;                                  // one unrolled trip per thread at least
   while ((M + rpb - 1) / rpb > 1024) rpb *= 2;
   const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
-  ProfScope ps("col_reduce", 4.0 * M * C, 0.0, s);
-  if (mode == 0)
-    hipLaunchKernelGGL(k_colstat4<0>, dim3(grid), dim3(256), 0, s, (const f32x4*)x, msum, msl, inv_m, out,
-                       nslots < 1 ? 1 : nslots, slot_stride, M, C4, rpb);
-  else
-    hipLaunchKernelGGL(k_colstat4<1>, dim3(grid), dim3(256), 0, s, (const f32x4*)x, msum, msl, inv_m, out,
-                       nslots < 1 ? 1 : nslots, slot_stride, M, C4, rpb);
+  ProfScope ps("col_reduce", (bf ? 2.0 : 4.0) * M * C, 0.0, s);
+  const int ns = nslots < 1 ? 1 : nslots;
+  if (bf) {
+    const V4<bf16_t> xv((const bf16_t*)x);
+    if (mode == 0) hipLaunchKernelGGL((k_colstat4<0, bf16_t>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb);
+    else hipLaunchKernelGGL((k_colstat4<1, bf16_t>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb);
+  } else {
+    const V4<float> xv(x);
+    if (mode == 0) hipLaunchKernelGGL((k_colstat4<0, float>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb);
+    else hipLaunchKernelGGL((k_colstat4<1, float>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb);
+  }
   return true;
 }
 

@@ -20,6 +20,17 @@
 
 using namespace mvae;
 
+namespace mvae {      // kernels_bf16.hip
+bool launch16_pw(bool transposed, const void* in, const float* w, const float* bias, const float* gate, const void* residual,
+                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s);
+bool launch16_dual(const void* X, const float* W, const void* aux, const float* gate, const void* residual, void* Y,
+                   float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C, GradSlots sl,
+                   hipStream_t s);
+bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g,
+                   hipStream_t s);
+bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s);
+}
+
 namespace {
 
 constexpr int kConvBaseFilters = 32;      // multiscale_vae.py:50
@@ -53,6 +64,7 @@ struct Block {
   MN mn;
 };
 struct Scale {
+  bool bf = false;                          // this scale's wide tensors are bfloat16 (MVAE_ACT_BF16 and every shape covered)
   int dg_total = 0;                         // sum of the blocks' gate-gradient slot copies
   int nmn = 0;                              // MobileNetV3 blocks of this scale (encoder + decoder)
   int H, W, C, z, z_off;
@@ -90,6 +102,8 @@ struct mvae_handle {
   std::vector<ParamInfo> params;
   std::vector<StateInfo> states;
   std::map<std::string, std::pair<int64_t, int64_t>> tensors;   // name -> (workspace float offset, elems per image)
+  std::map<std::string, int> tensor_dtype;                      // name -> MVAE_ACT_* (absent = float32)
+  bool kernel_gap = false;                                      // a bf16 launch found no kernel for its shape
   std::vector<Scale> scales;
   int64_t P = 0, S = 0, Z = 0, MET = 0;
   int64_t ws_floats = 0;
@@ -190,6 +204,13 @@ struct Builder {
     if (!name.empty()) h->tensors[name] = {o, per_image};
     return o;
   }
+  // a WIDE activation tensor: bfloat16 (half the floats) when the scale runs in bf16
+  int64_t actw(const std::string& name, int64_t per_image, bool bf) {
+    if (!bf) return act(name, per_image);
+    int64_t o = ws_alloc((per_image * maxB + 1) / 2);
+    if (!name.empty()) { h->tensors[name] = {o, per_image}; h->tensor_dtype[name] = MVAE_ACT_BF16; }
+    return o;
+  }
 };
 
 // offsets are stored as float* relative to a null base during planning and rebased at bind
@@ -198,6 +219,36 @@ inline float* rebase(float* p, float* base) {
   if (!p) return nullptr;
   intptr_t off = (reinterpret_cast<intptr_t>(p) - 4096) / 4;
   return base + off;
+}
+
+// Does every shape of the per-scale VAE at input size H x W have a bf16 kernel (kernels_bf16.hip + the storage-templated
+// VALU kernels)?  A scale that does not (the 8x8 / 4x4 tops of a deep pyramid, odd channel counts) stays float32: the
+// scales only meet in the 3-channel pyramid / merge tensors, which are float32 either way.
+bool scale_bf16_ok(const mvae_config& c, int H, int W) {
+  if (c.input_c != 3 && c.input_c != 1) return false;
+  auto map_ok = [](int h, int w, int ch) { return (ch == 32 || ch == 64) && ((int64_t)h * w) % 32 == 0 && h % 4 == 0; };
+  int ch = kConvBaseFilters, hh = H, ww = W;
+  if (!map_ok(hh, ww, ch)) return false;
+  auto walk = [&](int n, const int32_t* f, const int32_t* kh, const int32_t* kw, const int32_t* sh, const int32_t* sw, bool dec) {
+    for (int i = 0; i < n; ++i) {
+      if (sh[i] != 1 || sw[i] != 1 || f[i] != ch) {
+        const bool pw = kh[i] == 1 && kw[i] == 1 && sh[i] == 1 && sw[i] == 1;
+        const bool pair = (ch == 32 && f[i] == 64) || (ch == 64 && f[i] == 32);
+        if (!pair) return false;
+        if (!pw && !(kw[i] == 5 && kh[i] <= 8)) return false;
+        if (dec) { hh *= sh[i]; ww *= sw[i]; }
+        else { int o, p; same_pad(hh, kh[i], sh[i], &o, &p); hh = o; same_pad(ww, kw[i], sw[i], &o, &p); ww = o; }
+        ch = f[i];
+      }
+      if (!map_ok(hh, ww, ch)) return false;
+    }
+    return true;
+  };
+  if (!walk(c.enc_n, c.enc_filters, c.enc_kh, c.enc_kw, c.enc_sh, c.enc_sw, false)) return false;
+  const int64_t K = (int64_t)hh * ww * ch;
+  if (K < 256 || (K % 256) != 0) return false;
+  if (!walk(c.dec_n, c.dec_filters, c.dec_kh, c.dec_kw, c.dec_sh, c.dec_sw, true)) return false;
+  return (ch & (ch - 1)) == 0 && ch >= 4 && ch <= 256;
 }
 
 void build_mn(Builder& b, MN& m, const std::string& p, int c, int H, int W, Scale& sc) {
@@ -211,9 +262,9 @@ void build_mn(Builder& b, MN& m, const std::string& p, int c, int H, int W, Scal
   m.sw1 = b.param(p + ".se.d1.w", {c, c}, MVAE_REG_L1);       m.sb1 = b.param(p + ".se.d1.b", {c}, 0);
   m.w2 = b.param(p + ".conv2.w", {1, 1, c, c}, MVAE_REG_L1);  m.b2 = b.param(p + ".conv2.b", {c}, 0);
   int64_t hwc = (int64_t)H * W * c;
-  m.t0 = as_ptr(b.act(p + ".t0", hwc));
-  m.t1 = as_ptr(b.act(p + ".t1", hwc));
-  m.out = as_ptr(b.act(p + ".out", hwc));
+  m.t0 = as_ptr(b.actw(p + ".t0", hwc, sc.bf));
+  m.t1 = as_ptr(b.actw(p + ".t1", hwc, sc.bf));
+  m.out = as_ptr(b.actw(p + ".out", hwc, sc.bf));
   m.gap = as_ptr(b.act(p + ".gap", c));
   m.s0 = as_ptr(b.act(p + ".s0", c));
   m.xhat = as_ptr(b.act(p + ".xhat", c));
@@ -261,7 +312,8 @@ int build_plan(mvae_handle* h) {
     // ---- encoder (multiscale_vae.py:319-385)
     sc.cb_w = b.param(E + ".conv_base.w", {3, 3, C, kConvBaseFilters}, MVAE_REG_L2);
     sc.cb_b = b.param(E + ".conv_base.b", {kConvBaseFilters}, 0);
-    sc.e0 = as_ptr(b.act(E + ".conv_base", (int64_t)H * W * kConvBaseFilters));
+    sc.bf = c.act_dtype == MVAE_ACT_BF16 && 2 * c.z_dims[s] <= 32 && scale_bf16_ok(c, H, W);
+    sc.e0 = as_ptr(b.actw(E + ".conv_base", (int64_t)H * W * kConvBaseFilters, sc.bf));
     if ((int64_t)H * W * kConvBaseFilters > sc.scratch_elems) sc.scratch_elems = (int64_t)H * W * kConvBaseFilters;
     int ch = kConvBaseFilters, hh = H, ww = W;
     for (int i = 0; i < c.enc_n; ++i) {
@@ -278,7 +330,7 @@ int build_plan(mvae_handle* h) {
         blk.cw = b.param(bp + ".conv.w", {kh, kw, ch, f}, MVAE_REG_L1);
         blk.cb = b.param(bp + ".conv.b", {f}, 0);
         hh = g.OH; ww = g.OW; ch = f;
-        blk.cout = as_ptr(b.act(bp + ".conv", (int64_t)hh * ww * ch));
+        blk.cout = as_ptr(b.actw(bp + ".conv", (int64_t)hh * ww * ch, sc.bf));
       }
       build_mn(b, blk.mn, bp + ".mn", f, hh, ww, sc);
       sc.enc.push_back(blk);
@@ -292,7 +344,7 @@ int build_plan(mvae_handle* h) {
     sc.zs = as_ptr(b.act(E + ".z", sc.z));
     // ---- decoder (multiscale_vae.py:389-433)
     sc.dd_w = b.param(D + ".dense.w", {sc.z, sc.K}, MVAE_REG_L2);   sc.dd_b = b.param(D + ".dense.b", {sc.K}, 0);
-    sc.d0 = as_ptr(b.act(D + ".dense", sc.K));
+    sc.d0 = as_ptr(b.actw(D + ".dense", sc.K, sc.bf));
     for (int i = 0; i < c.dec_n; ++i) {
       Block blk;
       int f = c.dec_filters[i], kh = c.dec_kh[i], kw = c.dec_kw[i], sh = c.dec_sh[i], sw = c.dec_sw[i];
@@ -310,7 +362,7 @@ int build_plan(mvae_handle* h) {
         blk.cw = b.param(bp + ".convT.w", {kh, kw, f, ch}, MVAE_REG_L1);
         blk.cb = b.param(bp + ".convT.b", {f}, 0);
         hh = g.IH; ww = g.IW; ch = f;
-        blk.cout = as_ptr(b.act(bp + ".convT", (int64_t)hh * ww * ch));
+        blk.cout = as_ptr(b.actw(bp + ".convT", (int64_t)hh * ww * ch, sc.bf));
       }
       build_mn(b, blk.mn, bp + ".mn", f, hh, ww, sc);
       sc.dec.push_back(blk);
@@ -333,7 +385,7 @@ int build_plan(mvae_handle* h) {
     sc.y = as_ptr(b.act(D + ".y", hwC));
     sc.merged = (s == L - 1) ? sc.y : as_ptr(b.act("merged" + std::to_string(s), hwC));
     sc.dy = as_ptr(b.act("", hwC));
-    for (int k = 0; k < 4; ++k) sc.scratch[k] = as_ptr(b.act("", sc.scratch_elems));
+    for (int k = 0; k < 4; ++k) sc.scratch[k] = as_ptr(b.actw("", sc.scratch_elems, sc.bf));
     int64_t cm = sc.cmax;
     sc.dg = as_ptr(b.act("", cm * sc.dg_total)); sc.dgap = as_ptr(b.act("", cm));   // dg: [B, cmax] per slot copy
     sc.ds1 = as_ptr(b.act("", cm)); sc.dv = as_ptr(b.act("", cm));
@@ -351,7 +403,7 @@ int build_plan(mvae_handle* h) {
   h->keep_buf = as_ptr(b.act("keep_mask", C));
   h->recon = as_ptr(b.act("recon", hwC));
   h->losses = as_ptr(b.act("losses", 3 + L));
-  h->sgn = as_ptr(b.act("", 2 * C));
+  h->sgn = as_ptr(b.act("loss_sgn", 2 * C));
   h->reg_tmp = as_ptr(b.ws_alloc(kAlign));
   // optimiser tables
   for (size_t t = 0; t < h->params.size(); ++t) {
@@ -485,24 +537,33 @@ ConvGeom geom1x1(int B, int H, int W, int ci, int co) {
 }
 
 // ---- MobileNetV3 block (layer_blocks.py:556-648 with squeeze_excite_block :418-462) ----------
-void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipStream_t s) {
+// a bf16 launch must find a kernel: there is no silent fallback to another precision
+inline void need16(mvae_handle* h, bool ok) { if (!ok) h->kernel_gap = true; }
+
+void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipStream_t s, bool bf) {
   const float* P = h->dp;
   float* stats = h->dr + h->P;
   const int c = m.c;
+  const int64_t M = (int64_t)B * m.H * m.W, HW = (int64_t)m.H * m.W;
   ConvGeom g = geom1x1(B, m.H, m.W, c, c);
   PreOp none{nullptr, nullptr, nullptr};
-  bool tiled0;
-  {
-    ProfScope ps("k_conv0_tile", 8.0 * B * m.H * m.W * c, 2.0 * B * m.H * m.W * c * c, s);
-    tiled0 = launch_conv0_tile(x, P + m.w0, P + m.b0, nullptr, nullptr, m.t0, (int64_t)B * m.H * m.W, (int64_t)m.H * m.W, c, s);
+  if (bf) {
+    need16(h, launch16_pw(false, x, P + m.w0, P + m.b0, nullptr, nullptr, m.t0, M, HW, c, c, ACT_RELU, s));
+  } else {
+    bool tiled0;
+    {
+      ProfScope ps("k_conv0_tile", 8.0 * B * m.H * m.W * c, 2.0 * B * m.H * m.W * c * c, s);
+      tiled0 = launch_conv0_tile(x, P + m.w0, P + m.b0, nullptr, nullptr, m.t0, M, HW, c, s);
+    }
+    if (!tiled0) launch_conv_f(x, P + m.w0, P + m.b0, nullptr, m.t0, g, none, ACT_RELU, s);
   }
-  if (!tiled0) launch_conv_f(x, P + m.w0, P + m.b0, nullptr, m.t0, g, none, ACT_RELU, s);
   bool fused_dw;
   {
-    ProfScope ps(dw_uses_img(false, false, B, m.H, m.W, c) ? "k_dw_fwd_img" : "k_dw_fwd_ring<true>", 8.0 * B * m.H * m.W * c,
+    ProfScope ps(dw_uses_img(false, false, B, m.H, m.W, c) ? "k_dw_fwd_img" : "k_dw_fwd_ring<true>", (bf ? 4.0 : 8.0) * B * m.H * m.W * c,
                  20.0 * B * m.H * m.W * c, s);
-    fused_dw = launch_dw_fwd_gap(m.t0, P + m.wd, P + m.bd, m.t1, m.gap, B, m.H, m.W, c, s);
+    fused_dw = launch_dw_fwd_gap(m.t0, P + m.wd, P + m.bd, m.t1, m.gap, B, m.H, m.W, c, s, bf);
   }
+  if (bf) need16(h, fused_dw);
   if (!fused_dw) {
     launch_dw_fwd(m.t0, P + m.wd, P + m.bd, m.t1, B, m.H, m.W, c, s);
     launch_spatial_sum(m.t1, m.gap, B, (int64_t)m.H * m.W, c, 1.0f / (float)(m.H * m.W), s);
@@ -515,10 +576,14 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
                     stats + m.st_mean, stats + m.st_var, B, c, kSeBnEps, training ? 1 : 0, s);
     launch_gemm_nn(m.s1, P + m.sw1, P + m.sb1, m.g, m.ulin, B, c, c, ACT_HSIG, s);
   }
+  if (bf) {
+    need16(h, launch16_pw(false, m.t1, P + m.w2, P + m.b2, m.g, x, m.out, M, HW, c, c, ACT_NONE, s));
+    return;
+  }
   bool tiled2;
   {
     ProfScope ps("k_conv2_tile", 12.0 * B * m.H * m.W * c, 2.0 * B * m.H * m.W * c * c, s);
-    tiled2 = launch_conv0_tile(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, (int64_t)B * m.H * m.W, (int64_t)m.H * m.W, c, s);
+    tiled2 = launch_conv0_tile(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, M, HW, c, s);
   }
   if (!tiled2) {
     PreOp gate{m.g, nullptr, nullptr};
@@ -537,6 +602,24 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   ConvGeom g = geom1x1(B, m.H, m.W, c, c);
   PreOp none{nullptr, nullptr, nullptr};
   float* bufB = acquire(h, sc, s);
+  if (sc.bf) {
+    // the same chain on bf16 storage: conv2 pair, squeeze-excite backward, depthwise backward (ReLU mask from t1), conv0 pair
+    need16(h, launch16_dual(dout, P + m.w2, m.t1, m.g, nullptr, bufB, G + m.w2, G + m.b2, dg, (int64_t)B * HW, HW, c, h->gslots, s));
+    need16(h, launch_se_backward(dg, m.ulin, m.xhat, m.invstd, P + m.gam, P + m.bet, m.s0, m.gap, P + m.sw1, P + m.sw0, sc.ds1,
+                                 sc.dgap, G + m.sw1, G + m.sb1, G + m.gam, G + m.bet, G + m.sw0, G + m.sb0, m.se_part, B, c,
+                                 h->gslots, m.dg_slots, dg_stride, s));
+    float* bufC16 = acquire(h, sc, s);
+    {
+      ProfScope ps("k_dw_bwd_ring<false>", 8.0 * B * HW * c, 40.0 * B * HW * c, s);
+      need16(h, launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC16, G + m.wd, G + m.bd, h->gslots, false, B,
+                                    m.H, m.W, c, s, true));
+    }
+    need16(h, launch16_dual(bufC16, P + m.w0, x, nullptr, dout, bufB, G + m.w0, G + m.b0, nullptr, (int64_t)B * HW, HW, c,
+                            h->gslots, s));
+    release(sc, bufC16);
+    release(sc, dout);
+    return bufB;
+  }
   bool dual2;
   {
     ProfScope ps(c == 64 ? "k_gemm_dual<64, 1>" : "k_gemm_dual<32, 1>", 12.0 * B * HW * c, 4.0 * B * HW * c * c, s);   // rocprof kernel names
@@ -611,17 +694,24 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
   bool fused_dd;
   {
     ProfScope ps("dense_expand", 4.0 * (B * (double)sc.K + sc.K * sc.z), 2.0 * B * sc.K * sc.z, s);
-    fused_dd = launch_dense_expand(sc.zs, P + sc.dd_w, P + sc.dd_b, sc.d0, B, sc.z, (int)sc.K, s);
+    fused_dd = launch_dense_expand(sc.zs, P + sc.dd_w, P + sc.dd_b, sc.d0, B, sc.z, (int)sc.K, s, sc.bf);
   }
+  if (sc.bf) need16(h, fused_dd);
   if (!fused_dd) launch_gemm_nn(sc.zs, P + sc.dd_w, P + sc.dd_b, sc.d0, nullptr, B, sc.z, (int)sc.K, ACT_NONE, s);
   const float* x = sc.d0;
   for (Block& blk : sc.dec) {
     if (blk.has_conv) {
       ConvGeom g = blk.cg; g.B = B;
-      launch_conv_t(x, P + blk.cw, P + blk.cb, nullptr, blk.cout, g, s);
+      if (sc.bf) {
+        if (g.KH * g.KW == 1) need16(h, launch16_pw(true, x, P + blk.cw, P + blk.cb, nullptr, nullptr, blk.cout,
+                                                    (int64_t)B * g.IH * g.IW, (int64_t)g.IH * g.IW, g.CO, g.CI, ACT_NONE, s));
+        else need16(h, launch16_taps(true, x, P + blk.cw, P + blk.cb, blk.cout, g, s));
+      } else {
+        launch_conv_t(x, P + blk.cw, P + blk.cb, nullptr, blk.cout, g, s);
+      }
       x = blk.cout;
     }
-    mn_forward(h, blk.mn, x, B, training, s);
+    mn_forward(h, blk.mn, x, B, training, s, sc.bf);
     x = blk.mn.out;
   }
   const int64_t M = (int64_t)B * sc.H * sc.W;
@@ -629,9 +719,10 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
   // kStatSlots slot copies that the finalize kernel folds
   if (training) {
     launch_zero(sc.bn_sum, (int64_t)2 * kStatSlots * sc.dc, s);               // bn_sum and bn_sqdev are adjacent
-    if (!launch_colstat_opt(0, x, nullptr, 0, 0.f, sc.bn_sum, kStatSlots, sc.dc, M, sc.dc, s))
-      launch_colsum(x, sc.bn_sum, M, sc.dc, s);
-    if (!launch_colstat_opt(1, x, sc.bn_sum, kStatSlots, 1.0f / (float)M, sc.bn_sqdev, kStatSlots, sc.dc, M, sc.dc, s)) {
+    const bool cs0 = launch_colstat_opt(0, x, nullptr, 0, 0.f, sc.bn_sum, kStatSlots, sc.dc, M, sc.dc, s, sc.bf);
+    if (sc.bf) need16(h, cs0);
+    if (!cs0) launch_colsum(x, sc.bn_sum, M, sc.dc, s);
+    if (!launch_colstat_opt(1, x, sc.bn_sum, kStatSlots, 1.0f / (float)M, sc.bn_sqdev, kStatSlots, sc.dc, M, sc.dc, s, sc.bf)) {
       launch_bn2d_mean(sc.bn_sum, nullptr, sc.bn_mean, M, sc.dc, 1, s);
       launch_colsqdev(x, sc.bn_mean, sc.bn_sqdev, M, sc.dc, s);
     }
@@ -640,7 +731,9 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
                        sc.bn_mean, sc.bn_invstd, sc.bn_scale, sc.bn_shift, stats + sc.st_bn_mean,
                        stats + sc.st_bn_var, M, sc.dc, kDecBnEps, training ? 1 : 0, kStatSlots, s);
   ProfScope ps("head_fwd", 4.0 * M * (sc.dc + sc.C), 2.0 * M * sc.dc * sc.C, s);
-  if (!launch_head_fwd(x, sc.bn_scale, sc.bn_shift, P + sc.out_w, P + sc.out_b, sc.y, M, sc.dc, sc.C, s)) {
+  const bool hf = launch_head_fwd(x, sc.bn_scale, sc.bn_shift, P + sc.out_w, P + sc.out_b, sc.y, M, sc.dc, sc.C, s, sc.bf);
+  if (sc.bf) need16(h, hf);
+  if (!hf) {
     ConvGeom g = geom1x1(B, sc.H, sc.W, sc.dc, sc.C);
     PreOp bn{nullptr, sc.bn_scale, sc.bn_shift};
     launch_conv_f(x, P + sc.out_w, P + sc.out_b, nullptr, sc.y, g, bn, ACT_NONE, s);
@@ -933,25 +1026,33 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
       g.KH = g.KW = 3; g.SH = g.SW = 1; g.PT = g.PL = 1;
       {
         ProfScope ps("convbase_fwd", 4.0 * B * sc.H * sc.W * (C + kConvBaseFilters), 2.0 * B * sc.H * sc.W * 9 * C * kConvBaseFilters, ss);
-        if (!launch_convbase_fwd(sc.band, P + sc.cb_w, P + sc.cb_b, sc.e0, B, sc.H, sc.W, C, kConvBaseFilters, ss))
-          launch_conv_f(sc.band, P + sc.cb_w, P + sc.cb_b, nullptr, sc.e0, g, none, ACT_ELU, ss);
+        const bool cbf = launch_convbase_fwd(sc.band, P + sc.cb_w, P + sc.cb_b, sc.e0, B, sc.H, sc.W, C, kConvBaseFilters, ss, sc.bf);
+        if (sc.bf) need16(h, cbf);
+        if (!cbf) launch_conv_f(sc.band, P + sc.cb_w, P + sc.cb_b, nullptr, sc.e0, g, none, ACT_ELU, ss);
       }
       const float* x = sc.e0;
       for (Block& blk : sc.enc) {
         if (blk.has_conv) {
           ConvGeom cg = blk.cg; cg.B = B;
-          launch_conv_f(x, P + blk.cw, P + blk.cb, nullptr, blk.cout, cg, none, ACT_NONE, ss);
+          if (sc.bf) {
+            if (cg.KH * cg.KW == 1) need16(h, launch16_pw(false, x, P + blk.cw, P + blk.cb, nullptr, nullptr, blk.cout,
+                                                        (int64_t)B * cg.IH * cg.IW, (int64_t)cg.IH * cg.IW, cg.CI, cg.CO, ACT_NONE, ss));
+            else need16(h, launch16_taps(false, x, P + blk.cw, P + blk.cb, blk.cout, cg, ss));
+          } else {
+            launch_conv_f(x, P + blk.cw, P + blk.cb, nullptr, blk.cout, cg, none, ACT_NONE, ss);
+          }
           x = blk.cout;
         }
-        mn_forward(h, blk.mn, x, B, training, ss);
+        mn_forward(h, blk.mn, x, B, training, ss, sc.bf);
         x = blk.mn.out;
       }
       bool fused_heads;
       {
         ProfScope ps("dense_mu_lv", 4.0 * (B * (double)sc.K + 2.0 * sc.K * sc.z), 4.0 * B * sc.K * sc.z, ss);
         fused_heads = launch_dense_mu_lv(x, P + sc.mu_w, P + sc.mu_b, P + sc.lv_w, P + sc.lv_b, sc.mu, sc.lv, B,
-                                         (int)sc.K, sc.z, ss);
+                                         (int)sc.K, sc.z, ss, sc.bf);
       }
+      if (sc.bf) need16(h, fused_heads);
       if (!fused_heads) {
         launch_gemm_nn(x, P + sc.mu_w, P + sc.mu_b, sc.mu, nullptr, B, (int)sc.K, sc.z, ACT_NONE, ss);
         launch_gemm_nn(x, P + sc.lv_w, P + sc.lv_b, sc.lv, nullptr, B, (int)sc.K, sc.z, ACT_NONE, ss);
@@ -976,6 +1077,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
   if (rc != MVAE_OK) return rc;
   h->last_B = B; h->last_training = training; h->last_x = xsrc; h->last_eps = eps;
   if (training) h->last_train_B = B;
+  if (h->kernel_gap) return fail(h, MVAE_E_INVALID, "mvae_forward: a bfloat16 launch found no kernel for its shape");
   return check_launch(h, "mvae_forward");
 }
 
@@ -1020,8 +1122,9 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       launch_zero(sc.head_S, (int64_t)head_slots() * 2 * sc.dc, s);
       fused_head = launch_head_bwd(xbn, sc.dy, P + sc.out_w, P + sc.bn_g, sc.bn_scale, sc.bn_shift, sc.bn_mean,
                                    sc.bn_invstd, sc.head_S, G + sc.out_w, G + sc.out_b, G + sc.bn_g, G + sc.bn_b, d, M,
-                                   sc.dc, C, h->gslots, s);
+                                   sc.dc, C, h->gslots, s, sc.bf);
     }
+    if (sc.bf) need16(h, fused_head);
     if (!fused_head) {
       launch_zero(sc.bn_sum_d, (int64_t)(sc.dc), s);
       launch_zero(sc.bn_sum_dx, (int64_t)(sc.dc), s);
@@ -1039,7 +1142,11 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       d = mn_backward(h, sc, blk.mn, xin, d, B, s);
       if (blk.has_conv) {     // Conv2DTranspose: big = its output (d), small = its input (prev)
         ConvGeom g = blk.cg; g.B = B;
-        {
+        if (sc.bf) {
+          need16(h, launch16_wgrad(d, prev, G + blk.cw, nullptr, g, h->gslots, s));
+          need16(h, launch_colstat_opt(0, d, nullptr, 0, 0.f, h->gslots.at(G + blk.cb), h->gslots.count(), h->gslots.stride,
+                                       (int64_t)B * g.IH * g.IW, g.CI, s, true));
+        } else {
           hipStream_t w = wgrad_begin(h, sc, s);
           launch_conv_wgrad(d, prev, G + blk.cw, nullptr, g, none, h->gslots, w);
           if (!launch_colstat_opt(0, d, nullptr, 0, 0.f, h->gslots.at(G + blk.cb), h->gslots.count(), h->gslots.stride,
@@ -1048,7 +1155,13 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
           wgrad_reads(h, sc, d, w);
         }
         float* n = acquire(h, sc, s);
-        launch_conv_f(d, P + blk.cw, nullptr, nullptr, n, g, none, ACT_NONE, s);
+        if (sc.bf) {
+          if (g.KH * g.KW == 1) need16(h, launch16_pw(false, d, P + blk.cw, nullptr, nullptr, nullptr, n, (int64_t)B * g.IH * g.IW,
+                                                      (int64_t)g.IH * g.IW, g.CI, g.CO, ACT_NONE, s));
+          else need16(h, launch16_taps(false, d, P + blk.cw, nullptr, n, g, s));
+        } else {
+          launch_conv_f(d, P + blk.cw, nullptr, nullptr, n, g, none, ACT_NONE, s);
+        }
         release(sc, d);
         d = n;
       }
@@ -1059,8 +1172,9 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       bool fused_ddw;
       {
         ProfScope ps("dense_wgrad_dec", 4.0 * (B * (double)sc.K + sc.K * sc.z), 2.0 * B * sc.K * sc.z, w);
-        fused_ddw = launch_dense_wgrad_dec(sc.zs, d, G + sc.dd_w, G + sc.dd_b, B, sc.z, (int)sc.K, w);
+        fused_ddw = launch_dense_wgrad_dec(sc.zs, d, G + sc.dd_w, G + sc.dd_b, B, sc.z, (int)sc.K, w, sc.bf);
       }
+      if (sc.bf) need16(h, fused_ddw);
       if (!fused_ddw)
         launch_gemm_tn(sc.zs, d, G + sc.dd_w, G + sc.dd_b, B, sc.z, (int)sc.K, nullptr, nullptr, nullptr, w);
       wgrad_reads(h, sc, d, w);
@@ -1068,8 +1182,9 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     bool fused_dz;
     {
       ProfScope ps("dense_dz", 4.0 * (B * (double)sc.K + sc.K * sc.z), 2.0 * B * sc.K * sc.z, s);
-      fused_dz = launch_dense_dz(d, P + sc.dd_w, sc.dz, B, sc.z, (int)sc.K, s);
+      fused_dz = launch_dense_dz(d, P + sc.dd_w, sc.dz, B, sc.z, (int)sc.K, s, sc.bf);
     }
+    if (sc.bf) need16(h, fused_dz);
     if (!fused_dz) launch_gemm_nt(d, P + sc.dd_w, sc.dz, B, sc.z, (int)sc.K, nullptr, 0, s);
     launch_sample_kl_bwd(sc.dz, sc.mu, sc.lv, h->last_eps, (int)h->Z, sc.z_off, sc.dmu, sc.dlv,
                          h->d_hp, B, sc.z, s);
@@ -1080,8 +1195,9 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       {
         ProfScope ps("dense_wgrad", 4.0 * (B * (double)sc.K + 2.0 * sc.K * sc.z), 4.0 * B * sc.K * sc.z, w);
         fused_w = launch_dense_wgrad_mu_lv(flat, sc.dmu, sc.dlv, G + sc.mu_w, G + sc.lv_w, G + sc.mu_b, G + sc.lv_b, B,
-                                           (int)sc.K, sc.z, w);
+                                           (int)sc.K, sc.z, w, sc.bf);
       }
+      if (sc.bf) need16(h, fused_w);
       if (!fused_w) {
         launch_gemm_tn(flat, sc.dmu, G + sc.mu_w, G + sc.mu_b, B, (int)sc.K, sc.z, nullptr, nullptr, nullptr, w);
         launch_gemm_tn(flat, sc.dlv, G + sc.lv_w, G + sc.lv_b, B, (int)sc.K, sc.z, nullptr, nullptr, nullptr, w);
@@ -1092,8 +1208,9 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     bool fused_df;
     {
       ProfScope ps("dense_dflat", 4.0 * (B * (double)sc.K + 2.0 * sc.K * sc.z), 4.0 * B * sc.K * sc.z, s);
-      fused_df = launch_dense_dflat(sc.dmu, sc.dlv, P + sc.mu_w, P + sc.lv_w, d, B, (int)sc.K, sc.z, s);
+      fused_df = launch_dense_dflat(sc.dmu, sc.dlv, P + sc.mu_w, P + sc.lv_w, d, B, (int)sc.K, sc.z, s, sc.bf);
     }
+    if (sc.bf) need16(h, fused_df);
     if (!fused_df) {
       launch_gemm_nt(sc.dmu, P + sc.mu_w, d, B, (int)sc.K, sc.z, nullptr, 0, s);
       launch_gemm_nt(sc.dlv, P + sc.lv_w, d, B, (int)sc.K, sc.z, nullptr, 1, s);
@@ -1106,13 +1223,21 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       d = mn_backward(h, sc, blk.mn, xin, d, B, s);
       if (blk.has_conv) {     // Conv2D: big = its input (prev), small = its output (d)
         ConvGeom g = blk.cg; g.B = B;
-        {
+        if (sc.bf) {
+          need16(h, launch16_wgrad(prev, d, G + blk.cw, G + blk.cb, g, h->gslots, s));
+        } else {
           hipStream_t w = wgrad_begin(h, sc, s);
           launch_conv_wgrad(prev, d, G + blk.cw, G + blk.cb, g, none, h->gslots, w);
           wgrad_reads(h, sc, d, w);
         }
         float* n = acquire(h, sc, s);
-        launch_conv_t(d, P + blk.cw, nullptr, nullptr, n, g, s);
+        if (sc.bf) {
+          if (g.KH * g.KW == 1) need16(h, launch16_pw(true, d, P + blk.cw, nullptr, nullptr, nullptr, n, (int64_t)B * g.IH * g.IW,
+                                                      (int64_t)g.IH * g.IW, g.CO, g.CI, ACT_NONE, s));
+          else need16(h, launch16_taps(true, d, P + blk.cw, nullptr, n, g, s));
+        } else {
+          launch_conv_t(d, P + blk.cw, nullptr, nullptr, n, g, s);
+        }
         release(sc, d);
         d = n;
       }
@@ -1122,8 +1247,9 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     {
       ProfScope ps("convbase_wgrad", 4.0 * M * (2.0 * kConvBaseFilters + C), 2.0 * M * 9 * C * kConvBaseFilters, s);
       fused_base = launch_convbase_wgrad(sc.band, d, sc.e0, G + sc.cb_w, G + sc.cb_b, B, sc.H, sc.W, C,
-                                         kConvBaseFilters, h->gslots, s);
+                                         kConvBaseFilters, h->gslots, s, sc.bf);
     }
+    if (sc.bf) need16(h, fused_base);
     wgrad_join(h, sc, s);                       // every side-stream weight gradient of this scale is done
     if (!fused_base) {
       launch_elu_bwd(d, sc.e0, M * kConvBaseFilters, s);
@@ -1144,6 +1270,7 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
     rc = run_captured(h, fkey("B:%d", B), s0, body);
   else body(s0);
   if (rc != MVAE_OK) return rc;
+  if (h->kernel_gap) return fail(h, MVAE_E_INVALID, "mvae_backward: a bfloat16 launch found no kernel for its shape");
   return check_launch(h, "mvae_backward");
 }
 
@@ -1300,6 +1427,23 @@ int mvae_tensor_lookup(const mvae_handle* h, const char* name, float** ptr, int6
   if (ptr) *ptr = h->bound ? h->ws + it->second.first : nullptr;
   if (elems_per_image) *elems_per_image = it->second.second;
   return MVAE_OK;
+}
+
+int mvae_tensor_lookup2(const mvae_handle* h, const char* name, void** ptr, int64_t* elems_per_image, int32_t* dtype) {
+  float* p = nullptr;
+  const int rc = mvae_tensor_lookup(h, name, &p, elems_per_image);
+  if (rc != MVAE_OK) return rc;
+  if (ptr) *ptr = p;
+  if (dtype) {
+    auto it = h->tensor_dtype.find(name);
+    *dtype = it == h->tensor_dtype.end() ? MVAE_ACT_F32 : it->second;
+  }
+  return MVAE_OK;
+}
+
+int mvae_scale_dtype(const mvae_handle* h, int32_t scale) {
+  if (!h || scale < 0 || scale >= h->cfg.levels) return MVAE_E_INVALID;
+  return h->scales[scale].bf ? MVAE_ACT_BF16 : MVAE_ACT_F32;
 }
 
 }  // extern "C"

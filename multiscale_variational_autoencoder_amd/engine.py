@@ -364,12 +364,21 @@ class Engine:
         return out
 
     def tensor_nosync(self, name, batch):
-        p, n = C.c_void_p(), C.c_int64()
-        rc = self.lib.mvae_tensor_lookup(self.h, name.encode(), C.byref(p), C.byref(n))
+        """float32 view of a saved tensor (a bfloat16 tensor is converted: a copy)."""
+        p, n, dt = C.c_void_p(), C.c_int64(), C.c_int32()
+        rc = self.lib.mvae_tensor_lookup2(self.h, name.encode(), C.byref(p), C.byref(n), C.byref(dt))
         if rc != _abi.MVAE_OK:
             raise KeyError(name)
         off = (p.value - self.workspace.data_ptr()) // 4
+        if dt.value == _abi.ACT_DTYPES["bf16"]:
+            nfl = (batch * n.value + 1) // 2
+            with self.torch.cuda.stream(self.stream):
+                raw = self.workspace[off:off + nfl].view(self.torch.bfloat16)[:batch * n.value]
+                return raw.float().view(batch, n.value)
         return self.workspace[off:off + batch * n.value].view(batch, n.value)
+
+    def scale_dtypes(self):
+        return ["bf16" if self.lib.mvae_scale_dtype(self.h, s) == 1 else "f32" for s in range(self.levels)]
 
     def tensor(self, name, batch):
         """Debug/parity view of a saved intermediate of the last forward: [batch, elems_per_image]."""

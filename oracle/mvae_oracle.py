@@ -247,7 +247,9 @@ class Oracle:
     def set_kink_masks(self, masks):
         """masks: name -> bool array, '<block>.t0' / '.t1' / '.s0' (ReLU active) and '<block>.hsig' (inside the linear
         part of hard_sigmoid), flat [B, n] or in the tensor's NHWC / [B, C] shape.  None switches the override off."""
-        self.kink = None if masks is None else dict(masks=masks, report=dict(units=0, flips=0, max_abs_at_flip=0.0))
+        self.kink = None if masks is None else dict(masks=masks, report=dict(units=0, flips=0, max_abs_at_flip=0.0,
+                                                                             loss_units=0, loss_flips=0,
+                                                                             loss_max_abs_at_flip=0.0))
 
     def kink_report(self):
         return None if self.kink is None else dict(self.kink["report"])
@@ -262,14 +264,23 @@ class Oracle:
             m = m.reshape(x.shape)
         return m
 
-    def _account(self, own, m, dist):
+    def _account(self, own, m, dist, pre=""):
         rep = self.kink["report"]
         dis = own != m
         n = int(dis.sum())
-        rep["units"] += own.numel()
-        rep["flips"] += n
+        rep[pre + "units"] += own.numel()
+        rep[pre + "flips"] += n
         if n:
-            rep["max_abs_at_flip"] = max(rep["max_abs_at_flip"], float(dist[dis].max()))
+            rep[pre + "max_abs_at_flip"] = max(rep[pre + "max_abs_at_flip"], float(dist[dis].max()))
+
+    def _abs(self, d, name):
+        """|d| along the device's sign choice: masks[name] holds sign(d) as the device saw it (-1 / 0 / +1)."""
+        if self.kink is None or name not in self.kink["masks"]:
+            return d.abs()
+        sg = torch.as_tensor(np.asarray(self.kink["masks"][name]), dtype=d.dtype).reshape(d.shape)
+        dd = d.detach()
+        self._account(torch.sign(dd), sg, dd.abs(), "loss_")
+        return d * sg
 
     def _relu(self, x, name):
         m = self._mask_for(name, x)
@@ -400,7 +411,14 @@ class Oracle:
         for i in range(cfg.levels - 2, -1, -1):
             x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) + ys[i]
         v0, v1 = cfg.min_value, cfg.max_value
-        return torch.clamp((x + 1.0) * (v1 - v0) / 2.0 + v0, v0, v1)
+        lin = (x + 1.0) * (v1 - v0) / 2.0 + v0
+        if self.kink is not None and "loss.clip" in self.kink["masks"]:      # K.clip: inside [v0, v1] as the device saw it
+            m = torch.as_tensor(np.asarray(self.kink["masks"]["loss.clip"]).astype(bool))
+            m = m.reshape(lin.shape[0], lin.shape[2], lin.shape[3], lin.shape[1]).permute(0, 3, 1, 2)
+            ld = lin.detach()
+            self._account((ld >= v0) & (ld <= v1), m, torch.minimum((ld - v0).abs(), (ld - v1).abs()), "loss_")
+            return torch.where(m, lin, torch.clamp(ld, v0, v1))
+        return torch.clamp(lin, v0, v1)
 
     # -- full forward of the trainable model (multiscale_vae.py:261-288)
     def forward(self, T, state, x, eps, noise=None, mask=None, training=True, bn_group_size=None, inter=None):
@@ -443,11 +461,11 @@ class Oracle:
         yp = out["recon"]
         H, W = cfg.input_dims[0], cfg.input_dims[1]
         d0, d1 = int(H / 2), int(W / 2)
-        ap = (y - yp).abs()
+        ap = self._abs(y - yp, "loss.sign")
         r = ap.mean(dim=(1, 2, 3))                                                   # vae_r_loss :453-456
-        ch = (y.mean(dim=(1, 2)) - yp.mean(dim=(1, 2))).abs()
+        ch = self._abs(y.mean(dim=(1, 2)) - yp.mean(dim=(1, 2)), "loss.ch_sign")
         sl = (slice(None), slice(int(d0 / 2), int(d0 * 3 / 2)), slice(int(d1 / 2), int(d1 * 3 / 2)), slice(None))
-        cc = (y[sl].mean(dim=(1, 2)) - yp[sl].mean(dim=(1, 2))).abs()
+        cc = self._abs(y[sl].mean(dim=(1, 2)) - yp[sl].mean(dim=(1, 2)), "loss.cc_sign")
         r_exp = r + (ch.mean(dim=1) + cc.mean(dim=1)) / 2.0                          # :458-481
         mu, lv = out["mu"], out["log_var"]
         klt = -0.5 * (1.0 + lv - mu ** 2 - torch.exp(lv))                            # :485-488

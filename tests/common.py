@@ -127,10 +127,21 @@ def structurally_zero(ref):
     return {k for k, g in ref.items() if np.linalg.norm(np.asarray(g, np.float64).ravel()) < 1e-6 * rms * np.sqrt(np.asarray(g).size)}
 
 
-def device_kink_masks(eng, B):
+def device_kink_masks(eng, B, x=None, min_value=0.0, max_value=255.0):
     """The active sets the device used at every kink of the graph (ReLU outputs > 0, hard_sigmoid inputs inside
-    [-2.5, 2.5]), read back from the saved tensors of the last forward -- see Oracle.set_kink_masks."""
+    [-2.5, 2.5]), read back from the saved tensors of the last forward -- see Oracle.set_kink_masks.  With the input
+    batch `x` also the branches of the loss: sign(y - recon) per pixel, the signs of the two channel-mean terms and the
+    K.clip range mask (bfloat16 runs: the reconstruction error is large enough to flip those for a visible share of
+    the pixels, float32 runs do not need them)."""
     masks = {}
+    if x is not None:
+        H, W, C = eng.input_dims
+        recon = eng.tensor("recon", B).cpu().numpy().reshape(B, H, W, C)
+        masks["loss.sign"] = np.sign(np.asarray(x, np.float32) - recon)
+        sg = eng.tensor("loss_sgn", B).cpu().numpy().reshape(B, 2, C)
+        masks["loss.ch_sign"], masks["loss.cc_sign"] = sg[:, 0], sg[:, 1]
+        lin = (eng.tensor("merged0", B).cpu().numpy().reshape(B, H, W, C) + 1.0) * (max_value - min_value) * 0.5 + min_value
+        masks["loss.clip"] = (lin >= min_value) & (lin <= max_value)
     for k in eng.param_table:
         if not k.endswith(".mn.conv0.w"):
             continue

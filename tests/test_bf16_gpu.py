@@ -1,0 +1,138 @@
+"""GPU: the bfloat16-activation path (MVAE_ACT_BF16; BASELINE configs 4-5: 256x256x3, 7 scales, bf16) against the
+float64 oracle.  Storage of the wide [M,c] tensors is bfloat16, products run on v_mfma_f32_32x32x16_bf16 with float32
+accumulation; parameters, gradients, BatchNorm statistics and losses stay float32.
+
+The bar ("bf16 configs: report error, expect ~1e-2"), stated here and asserted below:
+  ELBO and its terms               <= 2e-2 relative
+  reconstruction                   <= 1.5e-2 * 255 RMS, 0.1 * 255 max over pixels (the decoder's BatchNorm subtracts the
+                                   batch mean of a bf16-stored tensor: a relative rounding error of 2^-9 of the VALUE
+                                   becomes (mean / std) times that after normalisation; measured 0.9 % RMS)
+  forward tensors (saved t0/t1/out) <= 2e-2 relative (norm-wise)
+  gradients, per tensor            <= 6e-2 * max(||ref||, 0.1 * rms * sqrt(n)), median over tensors <= 1.5e-2
+The oracle differentiates along the device's own branch at every kink (tests/common.py:device_kink_masks, now including
+the L1 loss signs and the clip mask): with bf16 forward errors of ~3e-3 a visible share of the ReLU units and loss signs
+sit on the other side than in float64, which is a property of the rounding, not of the kernels; the share is reported and
+bounded separately.  The float32 path keeps its own, 100x tighter bars (tests/test_parity_gpu.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.common import (COMPILE, CONFIGS, ROOT, device_kink_masks, engine_args, grad_errors, make_inputs,
+                          oracle_config, reg_grad, rel_err, structurally_zero)
+
+pytestmark = pytest.mark.gpu
+
+TOL16_ELBO = 2e-2
+TOL16_RECON_MAX = 0.1 * 255.0
+TOL16_RECON_RMS = 1.5e-2 * 255.0
+TOL16_FWD = 2e-2
+TOL16_GRAD = 6e-2
+TOL16_GRAD_MEDIAN = 1.5e-2
+KINK16_MAX_FRACTION = 2e-2      # share of ReLU / hard-sigmoid units on the other side of the kink than in float64
+KINK16_MAX_DISTANCE = 0.25      # and how far from the kink such a unit may be (activations are O(1))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def _engine(name, B):
+    from multiscale_variational_autoencoder_amd.engine import Engine
+    return Engine(**engine_args(name, B), act_dtype="bf16").bind()
+
+
+def _report(name, B, expect_bf16_scales):
+    from oracle.mvae_oracle import Oracle
+    io = make_inputs(name, B)
+    oc = oracle_config(name)
+    eng = _engine(name, B)
+    dts = eng.scale_dtypes()
+    assert dts[:expect_bf16_scales] == ["bf16"] * expect_bf16_scales, dts
+    eng.set_params(io["params"]); eng.set_state(io["state"])
+    d = {k: eng.to_device(io[k]) for k in ("x", "eps", "noise", "keep")}
+    out = eng.forward(d["x"], True, d["eps"], d["noise"], d["keep"], outputs=("recon", "mu", "log_var", "losses"))
+    eng.backward(COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+    eng.sync()
+    orc = Oracle(oc)
+    orc.set_kink_masks(device_kink_masks(eng, B, io["x"], oc.min_value, oc.max_value))
+    inter = {}
+    res, G = orc.loss_and_grads(io["params"], io["state"], io["x"], io["eps"], io["noise"], io["keep"],
+                                COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"], inter=inter)
+    rep = {"scale_dtypes": dts}
+    kr = orc.kink_report()
+    rep["kink"] = kr
+    losses = out["losses"].cpu().numpy().astype(np.float64)
+    elbo = (COMPILE["r_loss_factor"] * losses[:, 1] + COMPILE["kl_loss_factor"] * losses[:, 2]).mean()
+    rep["elbo_rel"] = abs(elbo - res["data_loss"]) / abs(res["data_loss"])
+    rep["r_rel"] = rel_err(losses[:, 0], res["r"]); rep["r_exp_rel"] = rel_err(losses[:, 1], res["r_exp"])
+    rep["kl_rel"] = rel_err(losses[:, 2], res["kl"])
+    rep["kl_scale_rel"] = rel_err(losses[:, 3:], res["kl_scale"])
+    dr = out["recon"].cpu().numpy().astype(np.float64) - res["recon"]
+    rep["recon_max"] = float(np.abs(dr).max()); rep["recon_rms"] = float(np.sqrt((dr ** 2).mean()))
+    rep["mu_rel"] = rel_err(out["mu"].cpu().numpy(), res["mu"])
+    fwd = {}
+    for k, v in inter.items():
+        if not k.endswith((".t0", ".t1", ".out", ".conv_base")):
+            continue
+        ref = v.detach().numpy()
+        if ref.ndim == 4:
+            ref = np.transpose(ref, (0, 2, 3, 1))
+        fwd[k] = rel_err(eng.tensor(k, B).cpu().numpy().reshape(ref.shape), ref)
+    rep["fwd_worst"] = max(fwd.items(), key=lambda kv: kv[1])
+    rep["fwd_median"] = float(np.median(list(fwd.values())))
+    g = eng.get_grads()
+    rg = reg_grad(io["params"], eng.param_table)
+    gerr = grad_errors({k: g[k].astype(np.float64) + rg[k] for k in G}, G)
+    zero = structurally_zero(G)
+    real = {k: v for k, v in gerr.items() if k not in zero}
+    rep["grad_worst"] = sorted(real.items(), key=lambda kv: -kv[1])[:8]
+    rep["grad_median"] = float(np.median(list(real.values())))
+    rep["grad_p90"] = float(np.percentile(list(real.values()), 90))
+    rep["grad_zero_worst"] = max(((k, gerr[k]) for k in zero), key=lambda kv: kv[1]) if zero else None
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_bf16_%s.json" % name), "w") as f:
+        json.dump(rep, f, indent=1, default=str)
+    print(json.dumps(rep, default=str))
+    return rep, eng
+
+
+def _check(rep):
+    kr = rep["kink"]
+    assert kr["flips"] <= KINK16_MAX_FRACTION * kr["units"], kr
+    assert kr["max_abs_at_flip"] <= KINK16_MAX_DISTANCE, kr
+    for k in ("elbo_rel", "r_rel", "r_exp_rel", "kl_rel", "kl_scale_rel"):
+        assert rep[k] <= TOL16_ELBO, (k, rep[k])
+    assert rep["recon_max"] <= TOL16_RECON_MAX and rep["recon_rms"] <= TOL16_RECON_RMS, (rep["recon_max"], rep["recon_rms"])
+    assert rep["fwd_worst"][1] <= TOL16_FWD, rep["fwd_worst"]
+    assert rep["grad_worst"][0][1] <= TOL16_GRAD, rep["grad_worst"]
+    assert rep["grad_median"] <= TOL16_GRAD_MEDIAN, rep["grad_median"]
+
+
+@pytest.mark.parametrize("name,B,nbf", [("c32nb", 8, 2), ("c64nb", 2, 3)])
+def test_bf16_forward_backward_parity(name, B, nbf):
+    rep, eng = _report(name, B, nbf)
+    _check(rep)
+
+
+@pytest.mark.timeout(1500)
+def test_bf16_c256nb_parity_and_full_batch_properties():
+    """BASELINE config 4's model in bf16: batch 2 against the oracle, then the full batch 64: finite, reconstruction in
+    range, the loss goes down under the optimiser (size-independent properties: the oracle is too slow at B = 64)."""
+    name = "c256nb"
+    rep, eng = _report(name, 2, 5)              # 256 .. 16 wide scales in bf16, the 8x8 and 4x4 tops in float32
+    _check(rep)
+    eng.close()
+    B = 64
+    eng = _engine(name, B)
+    from multiscale_variational_autoencoder_amd.initializers import init_params
+    eng.set_params(init_params(eng.param_table, 42))
+    x = eng.to_device(np.random.default_rng(2).uniform(0, 255, (B, 256, 256, 3)))
+    vals = []
+    for step in range(6):          # same seed every step: identical noise / dropout draws, so the losses are comparable
+        eng.train_step(x, 0.003, COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"], 1.0, seed=7)
+        m = eng.metrics()
+        vals.append(1000.0 * m["r_exp"] + 10.0 * m["vae_kl_loss"])
+    assert np.isfinite(vals).all() and min(vals[-2:]) < vals[0], vals
+    out = eng.forward(x, False, seed=3, outputs=("recon",))
+    r = out["recon"].cpu().numpy()
+    assert np.isfinite(r).all() and r.min() >= 0.0 and r.max() <= 255.0
+    assert np.isfinite(eng.params.cpu().numpy()).all()

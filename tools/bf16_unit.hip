@@ -1,0 +1,128 @@
+// Stand-alone check of kernels_bf16.hip against a double-precision CPU reference (bf16-rounded operands), one kernel at a
+// time.  Build (on the GPU box or here): hipcc --offload-arch=gfx950 -O2 tools/bf16_unit.hip csrc/kernels_bf16.o
+// csrc/kernels_generic.o csrc/dispatch.o ... -o bf16_unit   (see tools/run_bf16_unit.sh)
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../multiscale_variational_autoencoder_amd/csrc/kernels.h"
+using namespace mvae;
+namespace mvae {
+bool launch16_pw(bool transposed, const void* in, const float* w, const float* bias, const float* gate, const void* residual,
+                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s);
+bool launch16_dual(const void* X, const float* W, const void* aux, const float* gate, const void* residual, void* Y,
+                   float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C, GradSlots sl, hipStream_t s);
+bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g, hipStream_t s);
+bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s);
+}
+static uint16_t f2b(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static float b2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static float rb(float f) { return b2f(f2b(f)); }
+static float rnd() { return (float)rand() / RAND_MAX * 2.f - 1.f; }
+template <class T> T* dev(const std::vector<T>& v) { T* p; hipMalloc(&p, v.size() * sizeof(T)); hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return p; }
+template <class T> std::vector<T> host(const T* p, size_t n) { std::vector<T> v(n); hipMemcpy(v.data(), p, n * sizeof(T), hipMemcpyDeviceToHost); return v; }
+static double relerr(const std::vector<double>& ref, const std::vector<double>& got) {
+  double a = 0, b = 0; for (size_t i = 0; i < ref.size(); ++i) { a += (ref[i] - got[i]) * (ref[i] - got[i]); b += ref[i] * ref[i]; } return std::sqrt(a / (b + 1e-300));
+}
+static std::vector<double> b2d(const std::vector<uint16_t>& v) { std::vector<double> o(v.size()); for (size_t i = 0; i < v.size(); ++i) o[i] = b2f(v[i]); return o; }
+static std::vector<double> f2d(const std::vector<float>& v) { return std::vector<double>(v.begin(), v.end()); }
+
+static void test_pw(int K, int N, bool WT, bool gate, bool res, int act) {
+  const int B = 3, HW = 96; const int64_t M = (int64_t)B * HW;
+  std::vector<uint16_t> X(M * K), R(M * N); std::vector<float> W(K * N), bias(N), G(B * K);
+  for (auto& v : X) v = f2b(rnd()); for (auto& v : R) v = f2b(rnd()); for (auto& v : W) v = rnd() * 0.2f; for (auto& v : bias) v = rnd(); for (auto& v : G) v = 0.5f + 0.5f * rnd();
+  std::vector<double> ref(M * N);
+  for (int64_t m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
+    double a = 0; for (int k = 0; k < K; ++k) { float x = b2f(X[m * K + k]); if (gate) x = rb(x * G[(m / HW) * K + k]); a += (double)x * rb(WT ? W[n * K + k] : W[k * N + n]); }
+    a += bias[n]; if (act == ACT_RELU) a = a > 0 ? a : 0; if (res) a += b2f(R[m * N + n]); ref[m * N + n] = a;
+  }
+  auto dX = dev(X); auto dR = dev(R); auto dWt = dev(W); auto db = dev(bias); auto dG = dev(G); uint16_t* dY; hipMalloc(&dY, M * N * 2); hipMemset(dY, 0, M * N * 2);
+  bool ok = launch16_pw(WT, dX, dWt, db, gate ? dG : nullptr, res ? dR : nullptr, dY, M, HW, K, N, act, nullptr);
+  hipDeviceSynchronize();
+  printf("pw K=%d N=%d WT=%d gate=%d res=%d act=%d: launched=%d rel=%.3e\n", K, N, WT, gate, res, act, ok, relerr(ref, b2d(host(dY, M * N))));
+}
+static void test_dual(int C, int mode) {
+  const int B = 3, HW = 96; const int64_t M = (int64_t)B * HW;
+  std::vector<uint16_t> X(M * C), A(M * C), R(M * C); std::vector<float> W(C * C), G(B * C);
+  for (auto& v : X) v = f2b(rnd()); for (auto& v : A) v = f2b(rnd() + 0.3f); for (auto& v : R) v = f2b(rnd()); for (auto& v : W) v = rnd() * 0.2f; for (auto& v : G) v = 0.5f + 0.5f * rnd();
+  std::vector<double> Y(M * C), dW(C * C, 0.0), dbv(C, 0.0), dot(B * C, 0.0);
+  for (int64_t m = 0; m < M; ++m) for (int ci = 0; ci < C; ++ci) {
+    double a = 0, ae = 0; for (int co = 0; co < C; ++co) { a += (double)b2f(X[m * C + co]) * rb(W[ci * C + co]); ae += (double)b2f(X[m * C + co]) * W[ci * C + co]; }
+    if (mode == 2) a += b2f(R[m * C + ci]);
+    Y[m * C + ci] = a; dot[(m / HW) * C + ci] += ae * b2f(A[m * C + ci]);
+  }
+  for (int64_t m = 0; m < M; ++m) for (int ci = 0; ci < C; ++ci) { const double av = (double)b2f(A[m * C + ci]) * (mode == 1 ? G[(m / HW) * C + ci] : 1.0);
+    for (int co = 0; co < C; ++co) dW[ci * C + co] += av * b2f(X[m * C + co]); }
+  for (int64_t m = 0; m < M; ++m) for (int co = 0; co < C; ++co) dbv[co] += b2f(X[m * C + co]);
+  auto dX = dev(X); auto dA = dev(A); auto dR = dev(R); auto dWt = dev(W); auto dG = dev(G);
+  uint16_t* dY; hipMalloc(&dY, M * C * 2); float *gW, *gb, *gd; hipMalloc(&gW, C * C * 4); hipMalloc(&gb, C * 4); hipMalloc(&gd, B * C * 4);
+  hipMemset(gW, 0, C * C * 4); hipMemset(gb, 0, C * 4); hipMemset(gd, 0, B * C * 4);
+  GradSlots sl;
+  bool ok = launch16_dual(dX, dWt, dA, mode == 1 ? dG : nullptr, mode == 2 ? dR : nullptr, dY, gW, gb, mode == 1 ? gd : nullptr, M, HW, C, sl, nullptr);
+  hipDeviceSynchronize();
+  printf("dual C=%d mode=%d: launched=%d Y rel=%.3e dW rel=%.3e db rel=%.3e", C, mode, ok, relerr(Y, b2d(host(dY, M * C))), relerr(dW, f2d(host(gW, C * C))), relerr(dbv, f2d(host(gb, C))));
+  if (mode == 1) printf(" dot rel=%.3e", relerr(dot, f2d(host(gd, B * C))));
+  printf("\n");
+}
+static void conv_ref(const std::vector<uint16_t>& big, const std::vector<float>& W, const ConvGeom& g, std::vector<double>& small) {
+  small.assign((size_t)g.B * g.OH * g.OW * g.CO, 0.0);
+  for (int b = 0; b < g.B; ++b) for (int oh = 0; oh < g.OH; ++oh) for (int ow = 0; ow < g.OW; ++ow) for (int kh = 0; kh < g.KH; ++kh) for (int kw = 0; kw < g.KW; ++kw) {
+    int y = oh * g.SH + kh - g.PT, x = ow * g.SW + kw - g.PL; if (y < 0 || y >= g.IH || x < 0 || x >= g.IW) continue;
+    for (int ci = 0; ci < g.CI; ++ci) { double v = b2f(big[(((size_t)b * g.IH + y) * g.IW + x) * g.CI + ci]);
+      for (int co = 0; co < g.CO; ++co) small[(((size_t)b * g.OH + oh) * g.OW + ow) * g.CO + co] += v * rb(W[((kh * g.KW + kw) * g.CI + ci) * g.CO + co]); } }
+}
+static void test_taps(int CI, int CO, int IH, int IW) {
+  ConvGeom g{}; g.B = 2; g.IH = IH; g.IW = IW; g.CI = CI; g.CO = CO; g.KH = g.KW = 5; g.SH = g.SW = 2; g.OH = (IH + 1) / 2; g.OW = (IW + 1) / 2;
+  int tot = (g.OH - 1) * 2 + 5 - IH; g.PT = tot > 0 ? tot / 2 : 0; tot = (g.OW - 1) * 2 + 5 - IW; g.PL = tot > 0 ? tot / 2 : 0;
+  const size_t nb = (size_t)g.B * IH * IW * CI, ns = (size_t)g.B * g.OH * g.OW * CO;
+  std::vector<uint16_t> big(nb), small(ns); std::vector<float> W(25 * CI * CO), bias(CO), biasT(CI);
+  for (auto& v : big) v = f2b(rnd()); for (auto& v : small) v = f2b(rnd()); for (auto& v : W) v = rnd() * 0.1f; for (auto& v : bias) v = rnd(); for (auto& v : biasT) v = rnd();
+  // F-form
+  std::vector<double> ref; conv_ref(big, W, g, ref); for (size_t i = 0; i < ns; ++i) ref[i] += bias[i % CO];
+  auto dB = dev(big); auto dS = dev(small); auto dWt = dev(W); auto db = dev(bias); auto dbT = dev(biasT);
+  uint16_t *oS, *oB; hipMalloc(&oS, ns * 2); hipMalloc(&oB, nb * 2); hipMemset(oS, 0, ns * 2); hipMemset(oB, 0, nb * 2);
+  bool ok = launch16_taps(false, dB, dWt, db, oS, g, nullptr); hipDeviceSynchronize();
+  printf("taps F %d->%d %dx%d: launched=%d rel=%.3e\n", CI, CO, IH, IW, ok, relerr(ref, b2d(host(oS, ns))));
+  // T-form: big[b,y,x,ci] = biasT[ci] + sum small[...] W
+  std::vector<double> rt(nb, 0.0);
+  for (int b = 0; b < g.B; ++b) for (int oh = 0; oh < g.OH; ++oh) for (int ow = 0; ow < g.OW; ++ow) for (int kh = 0; kh < 5; ++kh) for (int kw = 0; kw < 5; ++kw) {
+    int y = oh * 2 + kh - g.PT, x = ow * 2 + kw - g.PL; if (y < 0 || y >= IH || x < 0 || x >= IW) continue;
+    for (int co = 0; co < CO; ++co) { double v = b2f(small[(((size_t)b * g.OH + oh) * g.OW + ow) * CO + co]);
+      for (int ci = 0; ci < CI; ++ci) rt[(((size_t)b * IH + y) * IW + x) * CI + ci] += v * rb(W[((kh * 5 + kw) * CI + ci) * CO + co]); } }
+  for (size_t i = 0; i < nb; ++i) rt[i] += biasT[i % CI];
+  ok = launch16_taps(true, dS, dWt, dbT, oB, g, nullptr); hipDeviceSynchronize();
+  printf("taps T %d->%d %dx%d: launched=%d rel=%.3e\n", CO, CI, IH, IW, ok, relerr(rt, b2d(host(oB, nb))));
+  // wgrad
+  std::vector<double> rw(25 * CI * CO, 0.0), rbias(CO, 0.0);
+  for (int b = 0; b < g.B; ++b) for (int oh = 0; oh < g.OH; ++oh) for (int ow = 0; ow < g.OW; ++ow) {
+    for (int co = 0; co < CO; ++co) rbias[co] += b2f(small[(((size_t)b * g.OH + oh) * g.OW + ow) * CO + co]);
+    for (int kh = 0; kh < 5; ++kh) for (int kw = 0; kw < 5; ++kw) { int y = oh * 2 + kh - g.PT, x = ow * 2 + kw - g.PL; if (y < 0 || y >= IH || x < 0 || x >= IW) continue;
+      for (int ci = 0; ci < CI; ++ci) { double v = b2f(big[(((size_t)b * IH + y) * IW + x) * CI + ci]);
+        for (int co = 0; co < CO; ++co) rw[((kh * 5 + kw) * CI + ci) * CO + co] += v * b2f(small[(((size_t)b * g.OH + oh) * g.OW + ow) * CO + co]); } } }
+  float *gW, *gb; hipMalloc(&gW, rw.size() * 4); hipMalloc(&gb, CO * 4); hipMemset(gW, 0, rw.size() * 4); hipMemset(gb, 0, CO * 4);
+  GradSlots sl; ok = launch16_wgrad(dB, dS, gW, gb, g, sl, nullptr); hipDeviceSynchronize();
+  printf("wgrad 5x5 %d,%d: launched=%d dW rel=%.3e db rel=%.3e\n", CI, CO, ok, relerr(rw, f2d(host(gW, rw.size()))), relerr(rbias, f2d(host(gb, CO))));
+}
+static void test_wgrad_pw(int CI, int CO) {
+  ConvGeom g{}; g.B = 3; g.IH = g.OH = 8; g.IW = g.OW = 12; g.CI = CI; g.CO = CO; g.KH = g.KW = g.SH = g.SW = 1;
+  const int64_t M = (int64_t)g.B * 96; std::vector<uint16_t> big(M * CI), small(M * CO);
+  for (auto& v : big) v = f2b(rnd()); for (auto& v : small) v = f2b(rnd());
+  std::vector<double> rw(CI * CO, 0.0), rbias(CO, 0.0);
+  for (int64_t m = 0; m < M; ++m) { for (int co = 0; co < CO; ++co) rbias[co] += b2f(small[m * CO + co]);
+    for (int ci = 0; ci < CI; ++ci) for (int co = 0; co < CO; ++co) rw[ci * CO + co] += (double)b2f(big[m * CI + ci]) * b2f(small[m * CO + co]); }
+  auto dB = dev(big); auto dS = dev(small); float *gW, *gb; hipMalloc(&gW, CI * CO * 4); hipMalloc(&gb, CO * 4); hipMemset(gW, 0, CI * CO * 4); hipMemset(gb, 0, CO * 4);
+  GradSlots sl; bool ok = launch16_wgrad(dB, dS, gW, gb, g, sl, nullptr); hipDeviceSynchronize();
+  printf("wgrad 1x1 %d,%d: launched=%d dW rel=%.3e db rel=%.3e\n", CI, CO, ok, relerr(rw, f2d(host(gW, CI * CO))), relerr(rbias, f2d(host(gb, CO))));
+}
+int main() {
+  srand(1);
+  test_pw(64, 64, false, false, false, ACT_RELU); test_pw(64, 64, false, true, true, ACT_NONE); test_pw(32, 32, false, true, true, ACT_NONE);
+  test_pw(64, 32, false, false, false, ACT_NONE); test_pw(32, 64, true, false, false, ACT_NONE); test_pw(64, 32, true, false, false, ACT_NONE); test_pw(32, 64, false, false, false, ACT_NONE);
+  test_dual(64, 1); test_dual(64, 2); test_dual(32, 1); test_dual(32, 2);
+  test_taps(32, 64, 16, 16); test_taps(64, 32, 16, 16); test_taps(32, 64, 12, 20);
+  test_wgrad_pw(64, 32); test_wgrad_pw(32, 64);
+  printf("last hip error: %s\n", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
