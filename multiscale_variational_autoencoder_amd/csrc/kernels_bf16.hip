@@ -123,11 +123,13 @@ __device__ __forceinline__ void load_wfrags(const float* __restrict__ W, int r, 
 }
 
 // epilogue of a transposed-orientation tile: acc[nt] holds channels nt*32 + 8q + 4h + e (e = reg & 3, q = reg >> 2) of
-// pixel row0 + r.  v = act(acc + bias) + residual, packed to bf16, two quads -> one 16-byte store.  The residual tile
+// pixel row0 + r.  v = act(acc + bias) + residual, packed to bf16, two quads -> one 16-byte store.  The bias sits in
+// registers (a per-tile bias load inside the tile loop came with its own s_waitcnt vmcnt(0), i.e. every tile waited for
+// the NEXT tile's prefetch: the first version ran at 2.8 TB/s, latency-bound).  The residual tile
 // was staged in LDS with the same coalesced 16-byte loads as the input (one tile ahead); here it is read back 8 bytes
 // per lane in the accumulator's layout.
-template <int N, bool RES>
-__device__ __forceinline__ void store_tile_t(const f32x16 (&acc)[N / 32], const float* __restrict__ bias, int act,
+template <int N, bool RES, int ACT, bool BIAS>
+__device__ __forceinline__ void store_tile_t(const f32x16 (&acc)[N / 32], const f32x4 (&bz)[N / 32][4],
                                              const char* __restrict__ res_tile, bf16_t* __restrict__ Y, int64_t row0, int r,
                                              int h) {
   const int64_t rowoff = (row0 + r) * N;
@@ -138,10 +140,10 @@ __device__ __forceinline__ void store_tile_t(const f32x16 (&acc)[N / 32], const 
     for (int q = 0; q < 4; ++q) {
       const int c0 = nt * 32 + 8 * q + 4 * h;
       f32x4 v = {acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
-      if (bias) v += *reinterpret_cast<const f32x4*>(bias + c0);
-      if (act != ACT_NONE) {
+      if constexpr (BIAS) v += bz[nt][q];
+      if constexpr (ACT != ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act16(v[e], act);
+        for (int e = 0; e < 4; ++e) v[e] = act16(v[e], ACT);
       }
       if constexpr (RES) v += unpack4(*reinterpret_cast<const uint2*>(res_tile + tile_off<N>(r, c0 >> 3) + (c0 & 7) * 2));
       pk[q] = pack4(v);
@@ -162,11 +164,11 @@ __device__ __forceinline__ void store_tile_t(const f32x16 (&acc)[N / 32], const 
 // (layer_blocks.py:594-602 conv0, :625-641 conv2, :946-951 the 1x1 Conv2D / Conv2DTranspose of basic_block)
 // block = 4 waves, wave = 32 rows (wave-private LDS tile, no block barrier); M % 32 == 0; gate: rows_per_image % 32 == 0
 // =================================================================================================
-template <int K, int N, bool WT, bool GATE, bool RES>
+template <int K, int N, bool WT, bool GATE, bool RES, int ACT>
 __global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, const float* __restrict__ W,
                                               const float* __restrict__ bias, const float* __restrict__ gate,
                                               const bf16_t* __restrict__ res, bf16_t* __restrict__ Y, int64_t ntiles,
-                                              int64_t rows_per_image, int act) {
+                                              int64_t rows_per_image) {
   constexpr int TB = 32 * K * 2, RB = RES ? 32 * N * 2 : 0;
   __shared__ __attribute__((aligned(16))) char lds[4 * (TB + RB)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -175,13 +177,28 @@ __global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, cons
   char* rtile = tile + TB;
   bf16x8 wf[N / 32][K / 16];
   load_wfrags<K, N, WT>(W, r, h, wf);
+  f32x4 bz[N / 32][4];
+#pragma unroll
+  for (int nt = 0; nt < N / 32; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bz[nt][q] = bias ? *reinterpret_cast<const f32x4*>(bias + nt * 32 + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t t = (int64_t)blockIdx.x * 4 + wave;
   TileRegs<K> cur, nxt;
   TileRegs<RES ? N : 16> rcur, rnxt;
+  // squeeze-excite gate of a tile's image: the lane's chunks all have channel chunk lane % (K/8), i.e. 8 gate values per
+  // tile.  They travel WITH the tile's prefetch (loaded one tile ahead): a gate load issued inside the tile would sit
+  // behind the next tile's prefetch in the in-order vmcnt queue, and waiting for it would drain that prefetch too.
+  f32x4 gc0 = {1.f, 1.f, 1.f, 1.f}, gc1 = gc0, gn0 = gc0, gn1 = gc0;
+  auto gate_load = [&](int64_t tile, f32x4& a, f32x4& b) {
+    const f32x4* gp = reinterpret_cast<const f32x4*>(gate + (tile * 32 / rows_per_image) * K + (lane % (K / 8)) * 8);
+    a = gp[0]; b = gp[1];
+  };
   if (t < ntiles) {
     tile_load<K>(X, t * 32, lane, cur);
     if constexpr (RES) tile_load<N>(res, t * 32, lane, rcur);
+    if constexpr (GATE) gate_load(t, gc0, gc1);
   }
   for (; t < ntiles; t += stride) {
     const int64_t row0 = t * 32;
@@ -189,15 +206,12 @@ __global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, cons
     tile_load<K>(X, tn * 32, lane, nxt);                       // next tile in flight under this tile's work
     if constexpr (RES) tile_load<N>(res, tn * 32, lane, rnxt);
     if constexpr (GATE) {
-      // lane's chunks all have channel chunk lane % (K/8): 8 gate values per tile (one image per wave tile)
-      const int64_t img = row0 / rows_per_image;
-      const f32x4* gp = reinterpret_cast<const f32x4*>(gate + img * K + (lane % (K / 8)) * 8);
-      const f32x4 g0 = gp[0], g1 = gp[1];
+      gate_load(tn, gn0, gn1);
 #pragma unroll
       for (int j = 0; j < K / 16; ++j) {
         const u32x4 u = cur.v[j];
-        float v[8] = {bf16_lo(u[0]) * g0[0], bf16_hi(u[0]) * g0[1], bf16_lo(u[1]) * g0[2], bf16_hi(u[1]) * g0[3],
-                      bf16_lo(u[2]) * g1[0], bf16_hi(u[2]) * g1[1], bf16_lo(u[3]) * g1[2], bf16_hi(u[3]) * g1[3]};
+        float v[8] = {bf16_lo(u[0]) * gc0[0], bf16_hi(u[0]) * gc0[1], bf16_lo(u[1]) * gc0[2], bf16_hi(u[1]) * gc0[3],
+                      bf16_lo(u[2]) * gc1[0], bf16_hi(u[2]) * gc1[1], bf16_lo(u[3]) * gc1[2], bf16_hi(u[3]) * gc1[3]};
         cur.v[j] = __builtin_bit_cast(u32x4, frag_of(v));
       }
     }
@@ -214,9 +228,10 @@ __global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, cons
 #pragma unroll
       for (int nt = 0; nt < N / 32; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][kk], xb, acc[nt], 0, 0, 0);
     }
-    store_tile_t<N, RES>(acc, bias, act, rtile, Y, row0, r, h);
+    store_tile_t<N, RES, ACT, true>(acc, bz, rtile, Y, row0, r, h);
     cur = nxt;
     if constexpr (RES) rcur = rnxt;
+    if constexpr (GATE) { gc0 = gn0; gc1 = gn1; }
   }
 }
 
@@ -266,6 +281,7 @@ __global__ void __launch_bounds__(256) k16_dual(const bf16_t* __restrict__ X, co
   float bsum[CT];
 #pragma unroll
   for (int a = 0; a < CT; ++a) bsum[a] = 0.f;
+  const f32x4 bz0[CT][4] = {};                                 // (no bias in the backward pair)
   // a wave takes a contiguous run of tiles that lies inside ONE image (launcher: tiles_per_wave divides
   // tiles_per_image), so the ungated product P = aux^T X accumulates in accw over the whole run; the gate scaling and
   // the gate gradient are applied once, after the loop
@@ -301,7 +317,7 @@ __global__ void __launch_bounds__(256) k16_dual(const bf16_t* __restrict__ X, co
       for (int nt = 0; nt < CT; ++nt)
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wfl[(nt * (C / 16) + kk) * 64 + lane]), xb, acc[nt], 0, 0, 0);
     }
-    store_tile_t<C, MODE == 2>(acc, nullptr, ACT_NONE, tr, Y, row0, r, h);
+    store_tile_t<C, MODE == 2, ACT_NONE, false>(acc, bz0, tr, Y, row0, r, h);
     // ---- P[co][ci] += X^T aux over the tile's 32 rows
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -672,16 +688,21 @@ bool launch16_pw(bool transposed, const void* in, const float* w, const float* b
   const bf16_t* R = (const bf16_t*)residual;
   bf16_t* Y = (bf16_t*)out;
   ProfScope ps("k16_pw", 2.0 * M * (K + N * (residual ? 2 : 1)), 2.0 * M * K * N, s);
+#define MVAE_PW1(KK, NN, WT_, G_, R_, A_)                                                                            \
+  hipLaunchKernelGGL((k16_pw<KK, NN, WT_, G_, R_, A_>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image)
 #define MVAE_PW(KK, NN, WT_)                                                                                          \
   if (K == KK && N == NN && transposed == WT_) {                                                                      \
-    if (gate && residual) hipLaunchKernelGGL((k16_pw<KK, NN, WT_, true, true>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image, act); \
-    else if (gate) hipLaunchKernelGGL((k16_pw<KK, NN, WT_, true, false>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image, act);       \
-    else if (residual) hipLaunchKernelGGL((k16_pw<KK, NN, WT_, false, true>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image, act);   \
-    else hipLaunchKernelGGL((k16_pw<KK, NN, WT_, false, false>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image, act);                \
+    if (act != ACT_NONE && (act != ACT_RELU || gate || residual)) return false;                                       \
+    if (gate && residual) MVAE_PW1(KK, NN, WT_, true, true, ACT_NONE);                                                \
+    else if (gate) MVAE_PW1(KK, NN, WT_, true, false, ACT_NONE);                                                      \
+    else if (residual) MVAE_PW1(KK, NN, WT_, false, true, ACT_NONE);                                                  \
+    else if (act == ACT_RELU) MVAE_PW1(KK, NN, WT_, false, false, ACT_RELU);                                          \
+    else MVAE_PW1(KK, NN, WT_, false, false, ACT_NONE);                                                               \
     return true;                                                                                                      \
   }
   MVAE_PW(64, 64, false) MVAE_PW(32, 32, false) MVAE_PW(64, 32, false) MVAE_PW(32, 64, false)
   MVAE_PW(64, 64, true) MVAE_PW(32, 32, true) MVAE_PW(64, 32, true) MVAE_PW(32, 64, true)
+#undef MVAE_PW1
 #undef MVAE_PW
   return false;
 }

@@ -21,11 +21,13 @@ struct DwGeom { int H, W, C4, XS, strips; };
 template <bool FUSE_GAP, typename T>
 __global__ void __launch_bounds__(256) k_dw_fwd_ring(const V4<T> in, const f32x4* __restrict__ w,
                                                      const f32x4* __restrict__ bias, const V4<T> out,
-                                                     float* __restrict__ gap, DwGeom g, float inv_hw) {
+                                                     float* __restrict__ gap, DwGeom g, float inv_hw, int nseg, int RS) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   f32x4* ring = reinterpret_cast<f32x4*>(dyn_lds);
   const int XSP = g.XS + 2;
-  const int b = blockIdx.y, x0 = blockIdx.x * g.XS;
+  // work item = (image b, row segment seg): rows [ya, ya + RS), RS % 4 == 0 (a block used to walk a whole image: at batch
+  // 64 the 64 .. 128 wide maps of the 256x256 configuration then gave 128 / 256 blocks for 256 CUs)
+  const int b = blockIdx.y / nseg, ya = (blockIdx.y % nseg) * RS, x0 = blockIdx.x * g.XS;
   const int xs_n = min(g.XS, g.W - x0);               // columns this strip really has
   const int c4 = threadIdx.x % g.C4;
   const int items = g.XS * g.C4;                      // <= 512: at most two items per thread
@@ -41,7 +43,7 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const V4<T> in, const f32x4
   // register FIFO of four rows, statically indexed by unrolling the row loop by four): with one or two resident blocks
   // per CU the bytes in flight per CU -- not the arithmetic -- set the rate of this kernel.
   typedef typename V4<T>::raw raw_t;
-  raw_t rv[4][3];
+  raw_t rv[4][3], rvm[3];
   auto fetch_row = [&](int y, raw_t (&r)[3]) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -62,17 +64,20 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const V4<T> in, const f32x4
   };
   f32x4 gsum[2];
   gsum[0] = gsum[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // H % 4 == 0 (launcher): the body below is straight-line code -- no uniform branches around the loads, so the
-  // compiler counts the outstanding loads exactly (s_waitcnt vmcnt(N), N > 0) instead of draining them.  Rows past the
-  // image are clamped to the last row: fetched and stored to a ring slot nobody reads.
+  // H % 4 == 0, ya % 4 == 0 (launcher): the body below is straight-line code -- no uniform branches around the loads, so
+  // the compiler counts the outstanding loads exactly (s_waitcnt vmcnt(N), N > 0) instead of draining them.  Rows past
+  // the image are clamped to the last row: fetched and stored to a ring slot nobody reads; row ya - 1 of the first
+  // segment likewise (slot 3, the taps with yy < 0 are skipped).
   const int yl = g.H - 1;
-  fetch_row(0, rv[0]);
-  fetch_row(1, rv[1]);
-  fetch_row(2, rv[2]);
-  fetch_row(3, rv[3]);
-  store_row(0, rv[0]);
-  fetch_row(min(4, yl), rv[0]);
-  for (int yb = 0; yb < g.H; yb += 4) {
+  fetch_row(max(ya - 1, 0), rvm);
+  fetch_row(ya, rv[0]);
+  fetch_row(ya + 1, rv[1]);
+  fetch_row(ya + 2, rv[2]);
+  fetch_row(ya + 3, rv[3]);
+  store_row(ya - 1, rvm);
+  store_row(ya, rv[0]);
+  fetch_row(min(ya + 4, yl), rv[0]);
+  for (int yb = ya; yb < ya + RS; yb += 4) {
 #pragma unroll
     for (int u4 = 0; u4 < 4; ++u4) {
       const int y = yb + u4;
@@ -115,7 +120,7 @@ __global__ void __launch_bounds__(256) k_dw_fwd_ring(const V4<T> in, const f32x4
       for (int r = threadIdx.x; r < 256; r += g.C4) t += red[r];
       t = t * inv_hw;
       float* gp = gap + (int64_t)b * g.C4 * 4 + threadIdx.x * 4;
-      if (g.strips == 1) {
+      if (g.strips * nseg == 1) {
         *reinterpret_cast<f32x4*>(gp) = t;
       } else {
 #pragma unroll
@@ -511,10 +516,16 @@ static bool run_dw_fwd_gap(const T* in, const float* w, const float* b, T* out, 
   }
   DwGeom g;
   size_t lds;
-  if (!dw_geom(H, W, C, &g, &lds) || B > 65535 || (H % 4) != 0) return false;
-  if (g.strips > 1) launch_zero(gap, (int64_t)B * C, s);
-  hipLaunchKernelGGL((k_dw_fwd_ring<true, T>), dim3(g.strips, B), dim3(256), lds, s, V4<T>(in), (const f32x4*)w,
-                     (const f32x4*)b, V4<T>(out), gap, g, 1.0f / (float)(H * W));
+  if (!dw_geom(H, W, C, &g, &lds) || (H % 4) != 0) return false;
+  // row segments until enough work items exist (bf16: ~1024 = four blocks per CU by LDS, half the bytes per block in
+  // flight; f32: 512, the launch shape the 32x32 headline configuration was tuned on); every segment re-reads two halo rows
+  const int64_t target = sizeof(T) == 2 ? 1024 : 512;
+  int nseg = 1;
+  while ((int64_t)B * g.strips * nseg < target && (H / (nseg * 2)) % 4 == 0 && H / (nseg * 2) >= 8) nseg *= 2;
+  if ((int64_t)B * nseg > 65535) return false;
+  if (g.strips * nseg > 1) launch_zero(gap, (int64_t)B * C, s);
+  hipLaunchKernelGGL((k_dw_fwd_ring<true, T>), dim3(g.strips, B * nseg), dim3(256), lds, s, V4<T>(in), (const f32x4*)w,
+                     (const f32x4*)b, V4<T>(out), gap, g, 1.0f / (float)(H * W), nseg, H / nseg);
   return true;
 }
 bool launch_dw_fwd_gap(const float* in, const float* w, const float* b, float* out, float* gap, int B, int H, int W,

@@ -374,7 +374,9 @@ class Engine:
             nfl = (batch * n.value + 1) // 2
             with self.torch.cuda.stream(self.stream):
                 raw = self.workspace[off:off + nfl].view(self.torch.bfloat16)[:batch * n.value]
-                return raw.float().view(batch, n.value)
+                out = raw.float().view(batch, n.value)
+            self.sync()          # the conversion ran on our stream: the caller reads the copy from another one
+            return out
         return self.workspace[off:off + batch * n.value].view(batch, n.value)
 
     def scale_dtypes(self):
