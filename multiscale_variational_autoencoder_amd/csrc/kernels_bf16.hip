@@ -128,7 +128,37 @@ __device__ __forceinline__ void load_wfrags(const float* __restrict__ W, int r, 
 // the NEXT tile's prefetch: the first version ran at 2.8 TB/s, latency-bound).  The residual tile
 // was staged in LDS with the same coalesced 16-byte loads as the input (one tile ahead); here it is read back 8 bytes
 // per lane in the accumulator's layout.
-template <int N, bool RES, int ACT, bool BIAS>
+// float32 result of a transposed-orientation tile: the register quad of lane (r, h) is 16 contiguous bytes of pixel row0+r.
+// Used where the consumer is a BatchNorm: the decoder's last block output keeps float32 storage, because normalisation
+// subtracts the batch mean and turns bf16's relative rounding error of the VALUE into (mean / std) times as much of the
+// normalised signal (measured: reconstruction RMS error 0.9 % of the range with a bf16 BatchNorm input).
+template <int N, bool RES, bool BIAS>
+__device__ __forceinline__ void store_tile_t32(const f32x16 (&acc)[N / 32], const f32x4 (&bz)[N / 32][4],
+                                               const char* __restrict__ res_tile, float* __restrict__ Y, int64_t row0, int r,
+                                               int h) {
+  const int64_t rowoff = (row0 + r) * N;
+#pragma unroll
+  for (int nt = 0; nt < N / 32; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c0 = nt * 32 + 8 * q + 4 * h;
+      f32x4 v = {acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
+      if constexpr (BIAS) v += bz[nt][q];
+      if constexpr (RES) v += unpack4(*reinterpret_cast<const uint2*>(res_tile + tile_off<N>(r, c0 >> 3) + (c0 & 7) * 2));
+      *reinterpret_cast<f32x4*>(Y + rowoff + c0) = v;
+    }
+}
+
+// two floats -> bf16 pair rounded to ONE bit less (nearest even at 2^17), the freed mantissa LSB of each carrying a mask
+// bit: the depthwise backward takes the ReLU mask (t1 > 0) from there instead of reading t1 (a quarter of its bytes)
+__device__ __forceinline__ unsigned pack_bf16_mask(float lo, float hi, bool mlo, bool mhi) {
+  const unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+  const unsigned ra = ((a + 0xFFFFu + ((a >> 17) & 1u)) & 0xFFFE0000u) | (mlo ? 0x10000u : 0u);
+  const unsigned rb = ((b + 0xFFFFu + ((b >> 17) & 1u)) & 0xFFFE0000u) | (mhi ? 0x10000u : 0u);
+  return (ra >> 16) | (rb & 0xFFFF0000u);
+}
+// MASK: res_tile is not added but supplies the mask source (aux = t1): the stored value carries (aux > 0) in its LSB
+template <int N, bool RES, int ACT, bool BIAS, bool MASK = false>
 __device__ __forceinline__ void store_tile_t(const f32x16 (&acc)[N / 32], const f32x4 (&bz)[N / 32][4],
                                              const char* __restrict__ res_tile, bf16_t* __restrict__ Y, int64_t row0, int r,
                                              int h) {
@@ -146,7 +176,14 @@ __device__ __forceinline__ void store_tile_t(const f32x16 (&acc)[N / 32], const 
         for (int e = 0; e < 4; ++e) v[e] = act16(v[e], ACT);
       }
       if constexpr (RES) v += unpack4(*reinterpret_cast<const uint2*>(res_tile + tile_off<N>(r, c0 >> 3) + (c0 & 7) * 2));
-      pk[q] = pack4(v);
+      if constexpr (MASK) {
+        const uint2 m = *reinterpret_cast<const uint2*>(res_tile + tile_off<N>(r, c0 >> 3) + (c0 & 7) * 2);
+        // aux = t1 >= 0 (a ReLU output): > 0 <=> any bit below the sign set
+        pk[q] = uint2{pack_bf16_mask(v[0], v[1], (m.x & 0x7FFFu) != 0u, (m.x & 0x7FFF0000u) != 0u),
+                      pack_bf16_mask(v[2], v[3], (m.y & 0x7FFFu) != 0u, (m.y & 0x7FFF0000u) != 0u)};
+      } else {
+        pk[q] = pack4(v);
+      }
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -164,10 +201,10 @@ __device__ __forceinline__ void store_tile_t(const f32x16 (&acc)[N / 32], const 
 // (layer_blocks.py:594-602 conv0, :625-641 conv2, :946-951 the 1x1 Conv2D / Conv2DTranspose of basic_block)
 // block = 4 waves, wave = 32 rows (wave-private LDS tile, no block barrier); M % 32 == 0; gate: rows_per_image % 32 == 0
 // =================================================================================================
-template <int K, int N, bool WT, bool GATE, bool RES, int ACT>
+template <int K, int N, bool WT, bool GATE, bool RES, int ACT, bool OUT32 = false>
 __global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, const float* __restrict__ W,
                                               const float* __restrict__ bias, const float* __restrict__ gate,
-                                              const bf16_t* __restrict__ res, bf16_t* __restrict__ Y, int64_t ntiles,
+                                              const bf16_t* __restrict__ res, void* __restrict__ Yv, int64_t ntiles,
                                               int64_t rows_per_image) {
   constexpr int TB = 32 * K * 2, RB = RES ? 32 * N * 2 : 0;
   __shared__ __attribute__((aligned(16))) char lds[4 * (TB + RB)];
@@ -228,7 +265,8 @@ __global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, cons
 #pragma unroll
       for (int nt = 0; nt < N / 32; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][kk], xb, acc[nt], 0, 0, 0);
     }
-    store_tile_t<N, RES, ACT, true>(acc, bz, rtile, Y, row0, r, h);
+    if constexpr (OUT32) store_tile_t32<N, RES, true>(acc, bz, rtile, static_cast<float*>(Yv), row0, r, h);
+    else store_tile_t<N, RES, ACT, true>(acc, bz, rtile, static_cast<bf16_t*>(Yv), row0, r, h);
     cur = nxt;
     if constexpr (RES) rcur = rnxt;
     if constexpr (GATE) { gc0 = gn0; gc1 = gn1; }
@@ -252,7 +290,7 @@ __global__ void __launch_bounds__(256) k16_dual(const bf16_t* __restrict__ X, co
                                                 const bf16_t* __restrict__ res, bf16_t* __restrict__ Y,
                                                 float* __restrict__ dW, float* __restrict__ db,
                                                 float* __restrict__ dot_out, int64_t ntiles, int64_t tiles_per_wave,
-                                                int64_t tiles_per_image, int nslots, int64_t slot_stride) {
+                                                int64_t tiles_per_image, int nslots, int64_t slot_stride, int embed_mask) {
   constexpr int CT = C / 32, TB = 32 * C * 2, NTL = MODE == 2 ? 3 : 2;    // tiles per wave in LDS: X, aux (, residual)
   constexpr int TILES = (4 * NTL * TB > C * C * 4) ? 4 * NTL * TB : C * C * 4;
   // the data GEMM's weight fragments live in LDS, one 16-byte slot per (fragment, lane): 32 registers less per lane
@@ -317,7 +355,12 @@ __global__ void __launch_bounds__(256) k16_dual(const bf16_t* __restrict__ X, co
       for (int nt = 0; nt < CT; ++nt)
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wfl[(nt * (C / 16) + kk) * 64 + lane]), xb, acc[nt], 0, 0, 0);
     }
-    store_tile_t<C, MODE == 2, ACT_NONE, false>(acc, bz0, tr, Y, row0, r, h);
+    if constexpr (MODE == 1) {
+      if (embed_mask) store_tile_t<C, false, ACT_NONE, false, true>(acc, bz0, ta, Y, row0, r, h);   // dt2 + ReLU mask of t1
+      else store_tile_t<C, false, ACT_NONE, false>(acc, bz0, ta, Y, row0, r, h);
+    } else {
+      store_tile_t<C, true, ACT_NONE, false>(acc, bz0, tr, Y, row0, r, h);
+    }
     // ---- P[co][ci] += X^T aux over the tile's 32 rows
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -397,18 +440,21 @@ __global__ void __launch_bounds__(256) k16_dual(const bf16_t* __restrict__ X, co
 // Same F-form / T-form coordinates as k_conv_taps (kernels_mfma.hip): F: out = small[B,OH,OW,NC=CO], in = big (KC = CI);
 // T: out = big[B,IH,IW,NC=CI], in = small (KC = CO), one sub-pixel phase per blockIdx.y.
 // A 512-thread block keeps the weight slices of ALL taps in LDS as bf16 [tap][n][k] (25 x 4 KB for 32 <-> 64): the tap
-// loop has no barrier.  A wave owns 32 output pixels x NC channels; per tap a lane fetches ITS pixel's KC channels for
-// its k-half straight from global memory (the MFMA B operand is 16 contiguous bytes of the NHWC row; SAME padding = an
-// out-of-range buffer offset, which returns zeros), one tap ahead of the MFMAs.
+// loop has no block barrier.  A wave owns 32 output pixels x NC channels; per tap it gathers the 32 input pixels' rows
+// with coalesced 16-byte loads (SAME padding = an out-of-range buffer offset, which returns zeros), one tap ahead of the
+// MFMAs, and stages them in a wave-private LDS tile from which the B fragments (lane = pixel) are read.
 // =================================================================================================
-template <int KC, int NC, bool TFORM, int MAXTAPS>
-__global__ void __launch_bounds__(512) k16_taps(const bf16_t* __restrict__ in, const float* __restrict__ W,
+template <int KC, int NC, bool TFORM, int MAXTAPS, int NTHR>
+__global__ void __launch_bounds__(NTHR) k16_taps(const bf16_t* __restrict__ in, const float* __restrict__ W,
                                                 const float* __restrict__ bias, bf16_t* __restrict__ out, ConvGeom g,
                                                 unsigned in_bytes, int tiles_per_wave) {
   constexpr int NT = NC / 32, KK = KC / 16;
+  constexpr int CPP = KC / 8, LX = KC / 16;          // 16-byte chunks per pixel; gather slots per lane (32 px * CPP / 64)
   __shared__ __attribute__((aligned(16))) char sW[MAXTAPS * NC * KC * 2];
+  __shared__ __attribute__((aligned(16))) char sA[(NTHR / 64) * 32 * KC * 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
+  char* myA = sA + wave * (32 * KC * 2);
   int py = 0, px = 0, CH = g.OH, CW = g.OW;
   if (TFORM) {
     py = blockIdx.y / g.SW; px = blockIdx.y % g.SW;
@@ -423,14 +469,14 @@ __global__ void __launch_bounds__(512) k16_taps(const bf16_t* __restrict__ in, c
   const int ntaps = nkh * nkw;
   // ---- this phase's weight slices -> LDS, bf16, [tap][n][k] with the 16-byte chunks of a row XOR-swizzled
   //      F: W[tap][k][n] (Keras HWIO);  T: W[tap][n][k] (the same array read with big = output channels)
-  for (int idx = threadIdx.x; idx < ntaps * NC * KC; idx += 512) {
+  for (int idx = threadIdx.x; idx < ntaps * NC * KC; idx += NTHR) {
     const int tl = idx / (NC * KC), rem = idx % (NC * KC);
     const int th = tl / nkw, tw = tl % nkw;
     const int tap = (kh0 + th * khs) * g.KW + kw0 + tw * kws;
     int n, k;
     if (TFORM) { n = rem / KC; k = rem % KC; } else { k = rem / NC; n = rem % NC; }
     const float v = W[(int64_t)tap * NC * KC + rem];
-    const int off = tl * NC * KC * 2 + n * KC * 2 + (((k >> 3) ^ (n & (KC / 8 - 1))) << 4) + (k & 7) * 2;
+    const int off = tl * NC * KC * 2 + n * KC * 2 + (((k >> 3) ^ ((KC == 32 ? n >> 1 : n) & (KC / 8 - 1))) << 4) + (k & 7) * 2;
     *reinterpret_cast<uint16_t*>(sW + off) = (uint16_t)(pack_bf16(v, 0.f) & 0xFFFFu);
   }
   __syncthreads();
@@ -449,57 +495,79 @@ __global__ void __launch_bounds__(512) k16_taps(const bf16_t* __restrict__ in, c
 #pragma unroll
       for (int e = 0; e < 4; ++e) bv[nt][q][e] = bias ? bias[nt * 32 + 8 * q + 4 * h + e] : 0.f;
 
-  const unsigned wtile0 = ((unsigned)blockIdx.x * 8u + wave) * (unsigned)tiles_per_wave;
+  const unsigned wtile0 = ((unsigned)blockIdx.x * (unsigned)(NTHR / 64) + wave) * (unsigned)tiles_per_wave;
   for (int ti = 0; ti < tiles_per_wave; ++ti) {
     const unsigned p0 = (wtile0 + ti) * 32u;
     if (p0 >= Mc) break;                                       // wave-uniform
-    const unsigned p = p0 + r;
-    int cx, cy, b;
-    split(p < Mc ? p : 0u, cx, cy, b);
-    const int y0 = TFORM ? cy : cy * g.SH, x0 = TFORM ? cx : cx * g.SW;
-    const unsigned base = (unsigned)(((b * SHh + y0) * SWw + x0) * KC + 8 * h) * 2u;
-    unsigned inv = p < Mc ? 0u : 0xFFFFu;
-    for (int t = 0; t < nkh; ++t) {
-      const int kh = kh0 + t * khs;
-      const int dy = TFORM ? (py + g.PT - kh) / g.SH : kh - g.PT;
-      if ((unsigned)(y0 + dy) >= (unsigned)SHh) inv |= 1u << t;
-    }
-    for (int t = 0; t < nkw; ++t) {
-      const int kw = kw0 + t * kws;
-      const int dx = TFORM ? (px + g.PL - kw) / g.SW : kw - g.PL;
-      if ((unsigned)(x0 + dx) >= (unsigned)SWw) inv |= 0x100u << t;
+    // The lane FETCHES 16-byte chunks of whole pixel rows (CPP lanes cover one pixel's KC channels: every load
+    // instruction reads full 128-byte lines; a lane-per-pixel gather of 32-byte pieces ran the texture path at an
+    // eighth of its rate) and the wave turns them into B fragments (lane = pixel) through its private LDS tile.
+    // slot j = pixel j*(64/CPP) + lane/CPP of the wave, chunk lane % CPP
+    unsigned base[LX], inv[LX];
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+      const unsigned p = p0 + (unsigned)(j * (64 / CPP) + lane / CPP);
+      int cx, cy, b;
+      split(p < Mc ? p : 0u, cx, cy, b);
+      const int y0 = TFORM ? cy : cy * g.SH, x0 = TFORM ? cx : cx * g.SW;
+      base[j] = (unsigned)(((b * SHh + y0) * SWw + x0) * KC + (lane % CPP) * 8) * 2u;
+      unsigned m = p < Mc ? 0u : 0xFFFFu;
+      for (int t = 0; t < nkh; ++t) {
+        const int kh = kh0 + t * khs;
+        const int dy = TFORM ? (py + g.PT - kh) / g.SH : kh - g.PT;
+        if ((unsigned)(y0 + dy) >= (unsigned)SHh) m |= 1u << t;
+      }
+      for (int t = 0; t < nkw; ++t) {
+        const int kw = kw0 + t * kws;
+        const int dx = TFORM ? (px + g.PL - kw) / g.SW : kw - g.PL;
+        if ((unsigned)(x0 + dx) >= (unsigned)SWw) m |= 0x100u << t;
+      }
+      inv[j] = m;
     }
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
-    u32x4 xb[KK], xn[KK];
-    auto fetch = [&](int th, int tw, u32x4 (&dst)[KK]) {
+    u32x4 xc[LX], xn[LX];
+    auto fetch = [&](int lin, u32x4 (&dst)[LX]) {               // tap number lin of this phase's list
+      const int th = lin / nkw, tw = lin - th * nkw;
       const int kh = kh0 + th * khs, kw = kw0 + tw * kws;
       const int dy = TFORM ? (py + g.PT - kh) / g.SH : kh - g.PT;
       const int dx = TFORM ? (px + g.PL - kw) / g.SW : kw - g.PL;
-      const unsigned off = (inv & ((1u << th) | (0x100u << tw))) ? 0x80000000u : base + (unsigned)((dy * SWw + dx) * KC * 2);
+      const unsigned delta = (unsigned)((dy * SWw + dx) * KC * 2);
+      const unsigned sel = (1u << th) | (0x100u << tw);
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) dst[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (unsigned)(kk * 32), 0, 0);
+      for (int j = 0; j < LX; ++j)
+        dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (inv[j] & sel) ? 0x80000000u : base[j] + delta, 0, 0);
     };
-    if (ntaps > 0) fetch(0, 0, xb);
-    int th = 0, tw = 0;
+    if (ntaps > 0) fetch(0, xc);
     for (int it = 0; it < ntaps; ++it) {
-      if (++tw == nkw) { tw = 0; ++th; }
-      if (it + 1 < ntaps) fetch(th, tw, xn);
+      if (it + 1 < ntaps) fetch(it + 1, xn);                    // next tap's rows in flight under this tap's work
+      WAVE_LDS_SYNC16();                                         // the previous tap's fragment reads are done
+#pragma unroll
+      for (int j = 0; j < LX; ++j) {
+        const int c = j * 64 + lane;
+        *reinterpret_cast<u32x4*>(myA + tile_off<KC>(c / CPP, c % CPP)) = xc[j];
+      }
+      WAVE_LDS_SYNC16();
       const char* wt = sW + it * NC * KC * 2;
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
+      for (int kk = 0; kk < KK; ++kk) {
+        const bf16x8 xb = frag_rows<KC>(myA, r, h, kk);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int n = nt * 32 + r;
-          const bf16x8 wa = as_frag(*reinterpret_cast<const u32x4*>(wt + n * KC * 2 + (((2 * kk + h) ^ (n & (KC / 8 - 1))) << 4)));
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, as_frag(xb[kk]), acc[nt], 0, 0, 0);
+          const bf16x8 wa = as_frag(*reinterpret_cast<const u32x4*>(wt + n * KC * 2 + (((2 * kk + h) ^ ((KC == 32 ? n >> 1 : n) & (KC / 8 - 1))) << 4)));
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[nt], 0, 0, 0);
         }
+      }
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) xb[kk] = xn[kk];
+      for (int j = 0; j < LX; ++j) xc[j] = xn[j];
     }
-    // ---- epilogue: bias, pack, 16-byte stores (pixels past the end are dropped)
-    // (the lane swaps below need every lane: only the store itself is masked)
+    // ---- epilogue: bias, pack, 16-byte stores (pixels past the end are dropped; the lane swaps need every lane, so only
+    //      the store itself is masked).  Lane r's OUTPUT pixel:
+    const unsigned p = p0 + r;
+    int cx, cy, b;
+    split(p < Mc ? p : 0u, cx, cy, b);
     const int64_t opix = TFORM ? ((int64_t)(b * g.IH + (cy * g.SH + py)) * g.IW + (cx * g.SW + px)) : (int64_t)(p < Mc ? p : 0u);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -530,7 +598,7 @@ __global__ void __launch_bounds__(512) k16_taps(const bf16_t* __restrict__ in, c
 // D[row = ci][col = co]: A = big^T, B = small, both read with ds_read_b64_tr_b16 from row-major wave-private tiles.
 // =================================================================================================
 template <int CI, int CO, int TG>
-__global__ void __launch_bounds__(256) k16_wgrad(const bf16_t* __restrict__ big, const bf16_t* __restrict__ small,
+__global__ void __launch_bounds__(256, 2) k16_wgrad(const bf16_t* __restrict__ big, const bf16_t* __restrict__ small,
                                                  float* __restrict__ dW, float* __restrict__ db, ConvGeom g, int64_t M,
                                                  int64_t rows_per_block, int nslots, int64_t slot_stride) {
   constexpr int KT = CI / 32, NT = CO / 32;
@@ -678,7 +746,7 @@ static int cus16() { return 256; }
 
 // 1x1 convolution forward / transposed.  false = shape not covered.
 bool launch16_pw(bool transposed, const void* in, const float* w, const float* bias, const float* gate, const void* residual,
-                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s) {
+                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s, bool out_f32) {
   if (M % 32 != 0 || M <= 0) return false;
   if (gate && (rows_per_image % 32 != 0)) return false;
   const int64_t ntiles = M / 32;
@@ -686,7 +754,15 @@ bool launch16_pw(bool transposed, const void* in, const float* w, const float* b
   const int grid = (int)(nblk < 4 * cus16() ? nblk : 4 * cus16());
   const bf16_t* X = (const bf16_t*)in;
   const bf16_t* R = (const bf16_t*)residual;
-  bf16_t* Y = (bf16_t*)out;
+  void* Y = out;
+  if (out_f32) {                                 // the conv2 of a decoder's last block: gate + residual, float32 result
+    if (!gate || !residual || transposed || act != ACT_NONE) return false;
+    ProfScope ps("k16_pw", 2.0 * M * (K + N) + 4.0 * M * N, 2.0 * M * K * N, s);
+    if (K == 32 && N == 32) hipLaunchKernelGGL((k16_pw<32, 32, false, true, true, ACT_NONE, true>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image);
+    else if (K == 64 && N == 64) hipLaunchKernelGGL((k16_pw<64, 64, false, true, true, ACT_NONE, true>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image);
+    else return false;
+    return true;
+  }
   ProfScope ps("k16_pw", 2.0 * M * (K + N * (residual ? 2 : 1)), 2.0 * M * K * N, s);
 #define MVAE_PW1(KK, NN, WT_, G_, R_, A_)                                                                            \
   hipLaunchKernelGGL((k16_pw<KK, NN, WT_, G_, R_, A_>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image)
@@ -710,7 +786,7 @@ bool launch16_pw(bool transposed, const void* in, const float* w, const float* b
 // MobileNetV3 backward pair (see k16_dual).  false = shape not covered.
 bool launch16_dual(const void* X, const float* W, const void* aux, const float* gate, const void* residual, void* Y,
                    float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C, GradSlots sl,
-                   hipStream_t s) {
+                   hipStream_t s, bool embed_mask) {
   if (M % 32 != 0 || rows_per_image % 32 != 0) return false;
   const int mode = (gate && dot_out && !residual) ? 1 : ((residual && !gate && !dot_out) ? 2 : 0);
   if (!mode || (C != 32 && C != 64)) return false;
@@ -725,7 +801,8 @@ bool launch16_dual(const void* X, const float* W, const void* aux, const float* 
                2.0 * M * C * (mode == 1 ? 3 : 4), 4.0 * M * C * C, s);
 #define MVAE_D16(CC, MM)                                                                                              \
   hipLaunchKernelGGL((k16_dual<CC, MM>), dim3(grid), dim3(256), 0, s, (const bf16_t*)X, W, (const bf16_t*)aux, gate,  \
-                     (const bf16_t*)residual, (bf16_t*)Y, sl.at(dW), sl.at(db), dot_out, ntiles, tpw, tpi, sl.count(), sl.stride)
+                     (const bf16_t*)residual, (bf16_t*)Y, sl.at(dW), sl.at(db), dot_out, ntiles, tpw, tpi, sl.count(), sl.stride, \
+                     embed_mask ? 1 : 0)
   if (C == 64) { if (mode == 1) MVAE_D16(64, 1); else MVAE_D16(64, 2); }
   else { if (mode == 1) MVAE_D16(32, 1); else MVAE_D16(32, 2); }
 #undef MVAE_D16
@@ -745,18 +822,24 @@ bool launch16_taps(bool transposed, const void* in, const float* w, const float*
   else Mc = (int64_t)g.B * g.OH * g.OW;
   const unsigned in_bytes = (unsigned)((int64_t)g.B * (transposed ? g.OH * g.OW : g.IH * g.IW) * KC * 2);
   const int64_t tiles = (Mc + 31) / 32;
-  int64_t waves = (int64_t)8 * cus16() / classes;              // one 512-thread block per CU (100 KB of weight slices)
-  if (waves < 8) waves = 8;
+  // The tap loop is a chain of (gather -> LDS -> MFMA) steps fed from L2 with one tap of prefetch: what hides the ~1 us
+  // of each gather is the number of waves per CU.  T-form phases stage at most 9 tap slices (36 KB): two 512-thread
+  // blocks per CU; F-form stages all 25 (100 KB): one block of 16 waves (KC = 32) or 12 (KC = 64: 4 KB tiles).
+  const int kWaves = transposed ? 8 : (KC == 32 ? 16 : 12);
+  const int per_cu = transposed ? 2 : 1;
+  int64_t waves = (int64_t)kWaves * per_cu * cus16() / classes;
+  if (waves < kWaves) waves = kWaves;
   if (waves > tiles) waves = tiles;
   const int tpw = (int)((tiles + waves - 1) / waves);
-  const unsigned gx = (unsigned)(((tiles + tpw - 1) / tpw + 7) / 8);
+  const unsigned gx = (unsigned)(((tiles + tpw - 1) / tpw + kWaves - 1) / kWaves);
   ProfScope ps(transposed ? "k16_taps<T>" : "k16_taps<F>", 2.0 * ((double)g.B * g.IH * g.IW * g.CI + (double)g.B * g.OH * g.OW * g.CO),
                2.0 * g.B * g.OH * g.OW * g.CO * g.KH * g.KW * g.CI, s);
-#define MVAE_T16(A, B_, TF)                                                                                           \
-  hipLaunchKernelGGL((k16_taps<A, B_, TF, 25>), dim3(gx, classes), dim3(512), 0, s, (const bf16_t*)in, w, bias,       \
-                     (bf16_t*)out, g, in_bytes, tpw)
-  if (KC == 32 && NC == 64) { if (transposed) MVAE_T16(32, 64, true); else MVAE_T16(32, 64, false); }
-  else { if (transposed) MVAE_T16(64, 32, true); else MVAE_T16(64, 32, false); }
+#define MVAE_T16(A, B_, TF, MT, NW)                                                                                   \
+  hipLaunchKernelGGL((k16_taps<A, B_, TF, MT, 64 * NW>), dim3(gx, classes), dim3(64 * NW), 0, s,                      \
+                     (const bf16_t*)in, w, bias, (bf16_t*)out, g, in_bytes, tpw)
+  if (transposed && (((g.KH + g.SH - 1) / g.SH) * ((g.KW + g.SW - 1) / g.SW) > 9)) return false;   // taps per phase
+  if (KC == 32 && NC == 64) { if (transposed) MVAE_T16(32, 64, true, 9, 8); else MVAE_T16(32, 64, false, 25, 16); }
+  else { if (transposed) MVAE_T16(64, 32, true, 9, 8); else MVAE_T16(64, 32, false, 25, 12); }
 #undef MVAE_T16
   return true;
 }

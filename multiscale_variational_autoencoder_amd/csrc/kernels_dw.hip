@@ -266,11 +266,16 @@ __global__ void __launch_bounds__(256) k_dw_bwd_ring(const V4<ST> dt2, const V4<
           const f32x4 rd = V4<ST>::cv(rdr[u]);
           f32x4 ra = rd;
           if constexpr (!LSB) ra = V4<ST>::cv(rar[u]);
+          // mask bit: the mantissa LSB of the STORED value (float: bit 0, kept in the value, <= 1 ulp; bf16: bit 16 of
+          // the widened pattern, cleared -- the producer rounded one bit shorter to make room for it)
+          constexpr unsigned kBit = sizeof(ST) == 2 ? 0x10000u : 1u;
           f32x4 v;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const bool on = LSB ? (__float_as_uint(rd[q]) & 1u) != 0u : ra[q] > 0.f;
-            v[q] = (ok && on) ? rd[q] * gg_c[q] + dg_c[q] : 0.f;
+            const unsigned bits = __float_as_uint(rd[q]);
+            const bool on = LSB ? (bits & kBit) != 0u : ra[q] > 0.f;
+            const float val = (LSB && sizeof(ST) == 2) ? __uint_as_float(bits & ~kBit) : rd[q];
+            v[q] = (ok && on) ? val * gg_c[q] + dg_c[q] : 0.f;
           }
           RING(y & 3, t / g.C4, c4) = v;
         }
@@ -404,7 +409,7 @@ __global__ void __launch_bounds__(256 * XS, XS == 2 ? 1 : 2) k_dw_bwd_img(const 
   for (int a = 0; a < 3; ++a) {
     const int yy = y - a + 1;
     rok[a] = yy >= 0 && yy < H;
-    rokm[a] = rok[a] ? 1u : 0u;
+    rokm[a] = rok[a] ? (sizeof(T) == 2 ? 0x10000u : 1u) : 0u;
     rowp[a] = tile + img * ipi + ((rok[a] ? yy : y) * W_ + x0) * C4 + c4;      // column x0 of the row
   }
   auto d1_at = [&](int a, int xx) {                            // column x0 + xx, inside the row
@@ -412,8 +417,10 @@ __global__ void __launch_bounds__(256 * XS, XS == 2 ? 1 : 2) k_dw_bwd_img(const 
     f32x4 v;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                              // branch-free: one select on (row valid) & (mask bit)
-      const float t = r[q] * gg[q] + dg[q];
-      v[q] = (__float_as_uint(r[q]) & rokm[a]) != 0u ? t : 0.f;
+      const unsigned bits = __float_as_uint(r[q]);
+      const float val = sizeof(T) == 2 ? __uint_as_float(bits & ~0x10000u) : r[q];   // bf16: the bit is not part of the value
+      const float t = val * gg[q] + dg[q];
+      v[q] = (bits & rokm[a]) != 0u ? t : 0.f;
     }
     return v;
   };
@@ -583,13 +590,13 @@ static bool run_dw_bwd_fused(const T* dt2, const T* t1, const T* t0, const float
                        sl.at(db), g, 1.0f / (float)(H * W), B, RS, nseg, sl.count(), sl.stride);
   return true;
 }
-// bf: bfloat16 storage (the ReLU mask then comes from t1: mask_in_lsb must be false)
+// bf: bfloat16 storage (mask_in_lsb: the producer k16_dual rounded dt2 one bit shorter and put the mask in the bf16 LSB)
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
                          const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
                          int W, int C, hipStream_t s, bool bf) {
   if (bf)
-    return !mask_in_lsb && run_dw_bwd_fused<bf16_t>((const bf16_t*)dt2, (const bf16_t*)t1, (const bf16_t*)t0, w, gate, dgap,
-                                                    (bf16_t*)dt0, dW, db, sl, false, B, H, W, C, s);
+    return run_dw_bwd_fused<bf16_t>((const bf16_t*)dt2, (const bf16_t*)t1, (const bf16_t*)t0, w, gate, dgap,
+                                    (bf16_t*)dt0, dW, db, sl, mask_in_lsb, B, H, W, C, s);
   return run_dw_bwd_fused<float>(dt2, t1, t0, w, gate, dgap, dt0, dW, db, sl, mask_in_lsb, B, H, W, C, s);
 }
 

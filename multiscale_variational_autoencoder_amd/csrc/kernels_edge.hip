@@ -374,12 +374,12 @@ __global__ void __launch_bounds__(256) k_head_bwd_reduce(const V4<T> x, const fl
 
 // backward pass 2 (apply): d[m,c] = gamma*invstd * (dxbn - S1/M - xhat * S2/M); block 0 also adds the BatchNorm
 // parameter gradients dgamma += S2, dbeta += S1
-template <int C, typename T>
+template <int C, typename T, typename TD>
 __global__ void __launch_bounds__(256) k_head_bwd_apply(const V4<T> x, const float* __restrict__ dy,
                                                         const float* __restrict__ W, const float* __restrict__ gamma,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ S,
-                                                        const V4<T> dout, float* __restrict__ dgamma,
+                                                        const V4<TD> dout, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int64_t M, int dc4, int nslots) {
   const int c4 = threadIdx.x % dc4, pl = threadIdx.x / dc4, ppb = 256 / dc4;
   const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
@@ -502,25 +502,25 @@ bool launch_head_fwd(const float* x, const float* scale, const float* shift, con
   return true;
 }
 int head_slots() { return kHeadSlots; }
-template <int C, typename T>
+template <int C, typename T, typename TD>
 static void run_head_bwd(const T* x, const float* dy, const float* W, const float* gamma, const float* scale,
                          const float* shift, const float* mean, const float* invstd, float* S, float* dW, float* db,
-                         float* dgamma, float* dbeta, T* dout, int64_t M, int dc, GradSlots sl, hipStream_t s) {
+                         float* dgamma, float* dbeta, TD* dout, int64_t M, int dc, GradSlots sl, hipStream_t s) {
   const int dc4 = dc / 4, npl = 256 / dc4;
   int64_t ppb = 16 * npl;                                  // >= 16 pixels per thread
   while ((M + ppb - 1) / ppb > 2048) ppb *= 2;
   hipLaunchKernelGGL((k_head_bwd_reduce<C, T>), dim3((unsigned)((M + ppb - 1) / ppb)), dim3(256), 0, s, V4<T>(x), dy, W,
                      scale, shift, mean, invstd, S, sl.at(dW), sl.at(db), M, dc4, ppb, sl.count(), sl.stride);
-  hipLaunchKernelGGL((k_head_bwd_apply<C, T>), dim3(cap_grid((M + 4 * npl - 1) / (4 * npl))), dim3(256), 0, s,
-                     V4<T>(x), dy, W, gamma, mean, invstd, S, V4<T>(dout), dgamma, dbeta, M, dc4, kHeadSlots);
+  hipLaunchKernelGGL((k_head_bwd_apply<C, T, TD>), dim3(cap_grid((M + 4 * npl - 1) / (4 * npl))), dim3(256), 0, s,
+                     V4<T>(x), dy, W, gamma, mean, invstd, S, V4<TD>(dout), dgamma, dbeta, M, dc4, kHeadSlots);
 }
-template <typename T>
+template <typename T, typename TD>
 static bool run_head_bwd_c(const T* x, const float* dy, const float* W, const float* gamma, const float* scale,
                            const float* shift, const float* mean, const float* invstd, float* S, float* dW, float* db,
-                           float* dgamma, float* dbeta, T* dout, int64_t M, int dc, int C, GradSlots sl, hipStream_t s) {
-  if (C == 3) run_head_bwd<3, T>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
-  else if (C == 1) run_head_bwd<1, T>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
-  else if (C == 4) run_head_bwd<4, T>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
+                           float* dgamma, float* dbeta, TD* dout, int64_t M, int dc, int C, GradSlots sl, hipStream_t s) {
+  if (C == 3) run_head_bwd<3, T, TD>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
+  else if (C == 1) run_head_bwd<1, T, TD>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
+  else if (C == 4) run_head_bwd<4, T, TD>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, sl, s);
   else return false;
   return true;
 }
@@ -530,10 +530,11 @@ bool launch_head_bwd(const float* x, const float* dy, const float* W, const floa
                      float* dgamma, float* dbeta, float* dout, int64_t M, int dc, int C, GradSlots sl, hipStream_t s, bool bf) {
   if (!head_ok(dc, C)) return false;
   // the reduce pass folds S into slot (block % kHeadSlots) and dW/db into gradient slot (block % sl.count())
+  // bf: the BatchNorm input x stays float32 (see store_tile_t32 in kernels_bf16.hip), the gradient leaves as bfloat16
   if (bf)
-    return run_head_bwd_c<bf16_t>((const bf16_t*)x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta,
-                                  (bf16_t*)dout, M, dc, C, sl, s);
-  return run_head_bwd_c<float>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, C, sl, s);
+    return run_head_bwd_c<float, bf16_t>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta,
+                                         (bf16_t*)dout, M, dc, C, sl, s);
+  return run_head_bwd_c<float, float>(x, dy, W, gamma, scale, shift, mean, invstd, S, dW, db, dgamma, dbeta, dout, M, dc, C, sl, s);
 }
 
 }  // namespace mvae

@@ -22,10 +22,10 @@ using namespace mvae;
 
 namespace mvae {      // kernels_bf16.hip
 bool launch16_pw(bool transposed, const void* in, const float* w, const float* bias, const float* gate, const void* residual,
-                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s);
+                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s, bool out_f32 = false);
 bool launch16_dual(const void* X, const float* W, const void* aux, const float* gate, const void* residual, void* Y,
                    float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C, GradSlots sl,
-                   hipStream_t s);
+                   hipStream_t s, bool embed_mask = false);
 bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g,
                    hipStream_t s);
 bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s);
@@ -48,6 +48,7 @@ struct ParamInfo { std::string name; int64_t shape[4]; int ndim; int64_t offset,
 struct StateInfo { std::string name; int64_t elems, offset; float momentum; int64_t per_image; };
 
 struct MN {
+  bool out_f32 = false;                     // bf16 scale: this block's output feeds the decoder BatchNorm and stays float32
   int c = 0, H = 0, W = 0;
   int dg_slots = 1, dg_prefix = 0;          // slot copies of this block's gate gradient, and where they start in Scale::dg
   int64_t w0, b0, wd, bd, sw0, sb0, gam, bet, sw1, sb1, w2, b2;
@@ -251,8 +252,9 @@ bool scale_bf16_ok(const mvae_config& c, int H, int W) {
   return (ch & (ch - 1)) == 0 && ch >= 4 && ch <= 256;
 }
 
-void build_mn(Builder& b, MN& m, const std::string& p, int c, int H, int W, Scale& sc) {
+void build_mn(Builder& b, MN& m, const std::string& p, int c, int H, int W, Scale& sc, bool out_f32 = false) {
   m.c = c; m.H = H; m.W = W;
+  m.out_f32 = out_f32 && sc.bf;
   m.w0 = b.param(p + ".conv0.w", {1, 1, c, c}, MVAE_REG_L1);  m.b0 = b.param(p + ".conv0.b", {c}, 0);
   m.wd = b.param(p + ".dw.w", {3, 3, c, 1}, MVAE_REG_L1);     m.bd = b.param(p + ".dw.b", {c}, 0);
   m.sw0 = b.param(p + ".se.d0.w", {c, c}, MVAE_REG_L1);       m.sb0 = b.param(p + ".se.d0.b", {c}, 0);
@@ -264,7 +266,7 @@ void build_mn(Builder& b, MN& m, const std::string& p, int c, int H, int W, Scal
   int64_t hwc = (int64_t)H * W * c;
   m.t0 = as_ptr(b.actw(p + ".t0", hwc, sc.bf));
   m.t1 = as_ptr(b.actw(p + ".t1", hwc, sc.bf));
-  m.out = as_ptr(b.actw(p + ".out", hwc, sc.bf));
+  m.out = as_ptr(b.actw(p + ".out", hwc, sc.bf && !m.out_f32));
   m.gap = as_ptr(b.act(p + ".gap", c));
   m.s0 = as_ptr(b.act(p + ".s0", c));
   m.xhat = as_ptr(b.act(p + ".xhat", c));
@@ -364,7 +366,7 @@ int build_plan(mvae_handle* h) {
         hh = g.IH; ww = g.IW; ch = f;
         blk.cout = as_ptr(b.actw(bp + ".convT", (int64_t)hh * ww * ch, sc.bf));
       }
-      build_mn(b, blk.mn, bp + ".mn", f, hh, ww, sc);
+      build_mn(b, blk.mn, bp + ".mn", f, hh, ww, sc, i == c.dec_n - 1);
       sc.dec.push_back(blk);
     }
     if (hh != H || ww != W)
@@ -577,7 +579,7 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
     launch_gemm_nn(m.s1, P + m.sw1, P + m.sb1, m.g, m.ulin, B, c, c, ACT_HSIG, s);
   }
   if (bf) {
-    need16(h, launch16_pw(false, m.t1, P + m.w2, P + m.b2, m.g, x, m.out, M, HW, c, c, ACT_NONE, s));
+    need16(h, launch16_pw(false, m.t1, P + m.w2, P + m.b2, m.g, x, m.out, M, HW, c, c, ACT_NONE, s, m.out_f32));
     return;
   }
   bool tiled2;
@@ -604,15 +606,17 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   float* bufB = acquire(h, sc, s);
   if (sc.bf) {
     // the same chain on bf16 storage: conv2 pair, squeeze-excite backward, depthwise backward (ReLU mask from t1), conv0 pair
-    need16(h, launch16_dual(dout, P + m.w2, m.t1, m.g, nullptr, bufB, G + m.w2, G + m.b2, dg, (int64_t)B * HW, HW, c, h->gslots, s));
+    need16(h, launch16_dual(dout, P + m.w2, m.t1, m.g, nullptr, bufB, G + m.w2, G + m.b2, dg, (int64_t)B * HW, HW, c, h->gslots, s,
+                            h->lsb_mask));
     need16(h, launch_se_backward(dg, m.ulin, m.xhat, m.invstd, P + m.gam, P + m.bet, m.s0, m.gap, P + m.sw1, P + m.sw0, sc.ds1,
                                  sc.dgap, G + m.sw1, G + m.sb1, G + m.gam, G + m.bet, G + m.sw0, G + m.sb0, m.se_part, B, c,
                                  h->gslots, m.dg_slots, dg_stride, s));
     float* bufC16 = acquire(h, sc, s);
     {
-      ProfScope ps("k_dw_bwd_ring<false>", 8.0 * B * HW * c, 40.0 * B * HW * c, s);
-      need16(h, launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC16, G + m.wd, G + m.bd, h->gslots, false, B,
-                                    m.H, m.W, c, s, true));
+      ProfScope ps(dw_uses_img(true, h->lsb_mask, B, m.H, m.W, c) ? "k_dw_bwd_img" : (h->lsb_mask ? "k_dw_bwd_ring<true>" : "k_dw_bwd_ring<false>"),
+                   (h->lsb_mask ? 6.0 : 8.0) * B * HW * c, 40.0 * B * HW * c, s);
+      need16(h, launch_dw_bwd_fused(bufB, m.t1, m.t0, P + m.wd, m.g, sc.dgap, bufC16, G + m.wd, G + m.bd, h->gslots,
+                                    h->lsb_mask, B, m.H, m.W, c, s, true));
     }
     need16(h, launch16_dual(bufC16, P + m.w0, x, nullptr, dout, bufB, G + m.w0, G + m.b0, nullptr, (int64_t)B * HW, HW, c,
                             h->gslots, s));
@@ -719,10 +723,11 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
   // kStatSlots slot copies that the finalize kernel folds
   if (training) {
     launch_zero(sc.bn_sum, (int64_t)2 * kStatSlots * sc.dc, s);               // bn_sum and bn_sqdev are adjacent
-    const bool cs0 = launch_colstat_opt(0, x, nullptr, 0, 0.f, sc.bn_sum, kStatSlots, sc.dc, M, sc.dc, s, sc.bf);
+    // (x = the last block's output: float32 storage in either mode, see MN::out_f32)
+    const bool cs0 = launch_colstat_opt(0, x, nullptr, 0, 0.f, sc.bn_sum, kStatSlots, sc.dc, M, sc.dc, s, false);
     if (sc.bf) need16(h, cs0);
     if (!cs0) launch_colsum(x, sc.bn_sum, M, sc.dc, s);
-    if (!launch_colstat_opt(1, x, sc.bn_sum, kStatSlots, 1.0f / (float)M, sc.bn_sqdev, kStatSlots, sc.dc, M, sc.dc, s, sc.bf)) {
+    if (!launch_colstat_opt(1, x, sc.bn_sum, kStatSlots, 1.0f / (float)M, sc.bn_sqdev, kStatSlots, sc.dc, M, sc.dc, s, false)) {
       launch_bn2d_mean(sc.bn_sum, nullptr, sc.bn_mean, M, sc.dc, 1, s);
       launch_colsqdev(x, sc.bn_mean, sc.bn_sqdev, M, sc.dc, s);
     }
@@ -731,7 +736,7 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
                        sc.bn_mean, sc.bn_invstd, sc.bn_scale, sc.bn_shift, stats + sc.st_bn_mean,
                        stats + sc.st_bn_var, M, sc.dc, kDecBnEps, training ? 1 : 0, kStatSlots, s);
   ProfScope ps("head_fwd", 4.0 * M * (sc.dc + sc.C), 2.0 * M * sc.dc * sc.C, s);
-  const bool hf = launch_head_fwd(x, sc.bn_scale, sc.bn_shift, P + sc.out_w, P + sc.out_b, sc.y, M, sc.dc, sc.C, s, sc.bf);
+  const bool hf = launch_head_fwd(x, sc.bn_scale, sc.bn_shift, P + sc.out_w, P + sc.out_b, sc.y, M, sc.dc, sc.C, s, false);
   if (sc.bf) need16(h, hf);
   if (!hf) {
     ConvGeom g = geom1x1(B, sc.H, sc.W, sc.dc, sc.C);
