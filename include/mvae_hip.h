@@ -157,6 +157,17 @@ int mvae_laplacian_split(int32_t device, const float* x, int32_t batch, int32_t 
 int mvae_laplacian_merge(int32_t device, const float* const* in, int32_t batch, int32_t H, int32_t W, int32_t C,
                          int32_t levels, float min_value, float max_value, float* out, float* work, void* stream);
 
+/* laplacian_transform_merge(trainable=True), forward (layer_blocks.py:137-171): per level i < levels-1, coarse to fine,
+ *      x = Concatenate([UpSampling2D(2, bilinear)(out), in[i]]) -> Conv2D(filters, 3x3, SAME, relu, bias) ->
+ *      Conv2D(C, 1x1, tanh, no bias);  out = x + in[i];  result = clip(denormalise(out)).
+ *      w3[i] [3,3,2C,filters], b3[i] [filters], w1[i] [1,1,filters,C]: device pointers for levels 0 .. levels-2 (host
+ *      arrays of pointers).  work: >= B*H*W*(2C + filters + 2C) floats.  The weights are the caller's: the reference
+ *      only ever builds this model, it has no training loop for it (and neither does this library). ---- */
+int mvae_laplacian_merge_mix(int32_t device, const float* const* in, int32_t batch, int32_t H, int32_t W, int32_t C,
+                             int32_t levels, int32_t filters, const float* const* w3, const float* const* b3,
+                             const float* const* w1, float min_value, float max_value, float* out, float* work,
+                             void* stream);
+
 /* ---- diagnostics (process-global): per-launch HIP-event timing on the launch stream, used by bench.py for
  *      the per-kernel roofline line.  report writes a JSON object {tag: {count, ms, bytes, flops}} (algorithmic
  *      bytes / flops summed over the launches), returns its length, and clears the records; it synchronises. ---- */

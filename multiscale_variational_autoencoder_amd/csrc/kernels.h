@@ -14,7 +14,7 @@ struct ConvGeom {
   int B, IH, IW, CI, OH, OW, CO, KH, KW, SH, SW, PT, PL;
 };
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_HSIG = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_HSIG = 3, ACT_TANH = 4 };
 
 struct PreOp {               // transform applied to the BIG-side operand when it is read
   const float* gate;         // [B,CI]  multiply (squeeze-excite gate), or null
@@ -45,6 +45,11 @@ void launch_blur_split(const float* in, float* band, float* down, int B, int H, 
 bool launch_lap_level(const float* in, float* diff, float* down, int B, int H, int W, int C, const float* gauss9,
                       bool normalise, float v0, float v1, hipStream_t s);
 void launch_denorm_clip(const float* in, float* out, int64_t n, float v0, float v1, hipStream_t s);
+// cat[b,y,x,:] = [up2(coarse)[b,y,x,:C], fine[b,y,x,:C]]   (Concatenate of layer_blocks.py:148-150); false: C > 8
+bool launch_lap_concat(const float* coarse, const float* fine, float* cat, int B, int H, int W, int C, hipStream_t s);
+// shape-generic convolution with any activation (ACT_TANH included): small = act(conv(big) + bias) + residual
+void launch_conv_f_any(const float* big, const float* w, const float* bias, const float* residual, float* small,
+                       ConvGeom g, int act, hipStream_t s);
 // out = up2(coarse) + fine; final_level: out = clip(denormalise(.)) instead (layer_blocks.py:123-131, 137-171)
 bool launch_lap_merge(const float* coarse, const float* fine, float* out, int B, int H, int W, int C, bool final_level,
                       float v0, float v1, hipStream_t s);

@@ -25,6 +25,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
   if (act == ACT_HSIG) return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);   // keras<=2.x hard_sigmoid
+  if (act == ACT_TANH) return tanhf(v);
   return v;
 }
 __device__ __forceinline__ float hsig_grad(float u) { return (u >= -2.5f && u <= 2.5f) ? 0.2f : 0.f; }
@@ -350,6 +351,38 @@ __global__ void __launch_bounds__(256) k_lap_merge(const float* __restrict__ coa
     }
   }
 }
+// Concatenate([UpSampling2D(2, bilinear)(coarse), fine]) of the trainable merge (layer_blocks.py:141-150)
+template <int C>
+__global__ void __launch_bounds__(256) k_lap_concat(const float* __restrict__ coarse, const float* __restrict__ fine,
+                                                    float* __restrict__ cat, unsigned B, unsigned H, unsigned W) {
+  const unsigned h = H / 2, w = W / 2, n = B * H * W;
+  for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    const unsigned x = p % W, q = p / W, y = q % H, b = q / H;
+    const unsigned iy = y >> 1, ix = x >> 1;
+    const unsigned y2 = (y & 1) ? min(iy + 1, h - 1) : (iy ? iy - 1 : 0u);
+    const unsigned x2 = (x & 1) ? min(ix + 1, w - 1) : (ix ? ix - 1 : 0u);
+    const float* cp = coarse + (size_t)b * h * w * C;
+    const float *p00 = cp + ((size_t)iy * w + ix) * C, *p01 = cp + ((size_t)iy * w + x2) * C;
+    const float *p10 = cp + ((size_t)y2 * w + ix) * C, *p11 = cp + ((size_t)y2 * w + x2) * C;
+    const float* ip = fine + (size_t)p * C;
+    float* op = cat + (size_t)p * 2 * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      op[c] = 0.75f * (0.75f * p00[c] + 0.25f * p01[c]) + 0.25f * (0.75f * p10[c] + 0.25f * p11[c]);   // as k_lap_merge
+      op[C + c] = ip[c];
+    }
+  }
+}
+bool launch_lap_concat(const float* coarse, const float* fine, float* cat, int B, int H, int W, int C, hipStream_t s) {
+  if (C < 1 || C > 8 || (int64_t)B * H * W >= (1ll << 31)) return false;
+  const unsigned gf = (unsigned)grid_for((int64_t)B * H * W);
+  switch (C) {
+#define MVAE_LC(C_) case C_: hipLaunchKernelGGL((k_lap_concat<C_>), dim3(gf), dim3(256), 0, s, coarse, fine, cat, (unsigned)B, (unsigned)H, (unsigned)W); break;
+    MVAE_LC(1) MVAE_LC(2) MVAE_LC(3) MVAE_LC(4) MVAE_LC(5) MVAE_LC(6) MVAE_LC(7) MVAE_LC(8)
+#undef MVAE_LC
+  }
+  return true;
+}
 bool launch_lap_merge(const float* coarse, const float* fine, float* out, int B, int H, int W, int C, bool final_level,
                       float v0, float v1, hipStream_t s) {
   if (C < 1 || C > 8 || (int64_t)B * H * W >= (1ll << 31)) return false;
@@ -430,6 +463,13 @@ __global__ void k_conv_f(const float* __restrict__ big, const float* __restrict_
     if (residual) acc += residual[i];
     small[i] = acc;
   }
+}
+void launch_conv_f_generic(const float* big, const float* w, const float* bias, const float* residual, float* small,
+                           ConvGeom g, PreOp pre, int act, hipStream_t s);
+void launch_conv_f_any(const float* big, const float* w, const float* bias, const float* residual, float* small,
+                       ConvGeom g, int act, hipStream_t s) {
+  PreOp none{nullptr, nullptr, nullptr};
+  launch_conv_f_generic(big, w, bias, residual, small, g, none, act, s);
 }
 void launch_conv_f_generic(const float* big, const float* w, const float* bias, const float* residual, float* small,
                            ConvGeom g, PreOp pre, int act, hipStream_t s) {

@@ -1391,6 +1391,41 @@ int mvae_laplacian_merge(int32_t device, const float* const* in, int32_t batch, 
   return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
 }
 
+int mvae_laplacian_merge_mix(int32_t device, const float* const* in, int32_t batch, int32_t H, int32_t W, int32_t C,
+                             int32_t levels, int32_t filters, const float* const* w3, const float* const* b3,
+                             const float* const* w1, float min_value, float max_value, float* out, float* work,
+                             void* stream) {
+  if (!in || !out || !work || !w3 || !b3 || !w1 || batch <= 0 || C <= 0 || C > 8 || filters <= 0 || levels < 1 ||
+      levels > MVAE_MAX_LEVELS)
+    return MVAE_E_INVALID;
+  if (H <= 0 || W <= 0 || (H % (1 << (levels - 1))) || (W % (1 << (levels - 1)))) return MVAE_E_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n0 = (int64_t)batch * H * W;
+  if (levels == 1) {
+    launch_denorm_clip(in[0], out, n0 * C, min_value, max_value, s);
+    return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
+  }
+  float* cat = work;                         // [B,H,W,2C]
+  float* hid = cat + n0 * 2 * C;             // [B,H,W,filters]
+  float* run[2] = {hid + n0 * filters, hid + n0 * filters + n0 * C};
+  const float* coarse = in[levels - 1];
+  for (int i = levels - 2; i >= 0; --i) {
+    const int h = H >> i, w = W >> i;
+    if (!launch_lap_concat(coarse, in[i], cat, batch, h, w, C, s)) return MVAE_E_INVALID;
+    ConvGeom g3{};
+    g3.B = batch; g3.IH = g3.OH = h; g3.IW = g3.OW = w; g3.CI = 2 * C; g3.CO = filters;
+    g3.KH = g3.KW = 3; g3.SH = g3.SW = 1; g3.PT = g3.PL = 1;
+    launch_conv_f_any(cat, w3[i], b3[i], nullptr, hid, g3, ACT_RELU, s);                       // mixing
+    ConvGeom g1 = geom1x1(batch, h, w, filters, C);
+    float* dst = run[i & 1];
+    launch_conv_f_any(hid, w1[i], nullptr, in[i], dst, g1, ACT_TANH, s);                       // retargeting + Add
+    coarse = dst;
+  }
+  launch_denorm_clip(coarse, out, n0 * C, min_value, max_value, s);
+  return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
+}
+
 int mvae_profile_enable(int32_t on) {
   Profiler& p = profiler();
   p.on = on != 0;

@@ -4,8 +4,10 @@ section 8(f) rank 3).  Same factory signatures; the returned objects are callabl
 returns (`model(x)` / `model.predict(x)`), take / return NHWC float arrays and run `mvae_laplacian_split` /
 `mvae_laplacian_merge` of libmvae_hip.so on `cuda:0`.  There is no CPU fallback.
 
-Not built: `laplacian_transform_merge(trainable=True)` (the conv-mixing variant, layer_blocks.py:147-170): it owns
-trainable weights and belongs with a training graph this build does not have for it."""
+`laplacian_transform_merge(trainable=True)` (the conv-mixing variant, layer_blocks.py:147-170) is built as a FORWARD
+model: it owns its Conv2D weights (glorot_normal, `get_weights()` / `set_weights()`), runs `mvae_laplacian_merge_mix`,
+and has no training loop -- the reference never trains it either (nothing in the reference calls it with
+trainable=True)."""
 import ctypes as C
 
 import numpy as np
@@ -124,6 +126,75 @@ class LaplacianMerge(_HipModel):
         return out.cpu().numpy()
 
 
+class LaplacianMergeMix(LaplacianMerge):
+    """laplacian_transform_merge(trainable=True): per level Concatenate([up2(out), level]) -> Conv2D(filters, 3x3, relu)
+    -> Conv2D(C, 1x1, tanh, no bias) -> Add (layer_blocks.py:141-171)."""
+
+    def __init__(self, input_dims, levels, name, min_value, max_value, filters, activation, kernel_initializer, seed=42,
+                 device=0):
+        super().__init__(input_dims, levels, name, min_value, max_value, device)
+        if activation != "relu":
+            raise ValueError("the HIP path implements the reference's default activation ('relu')")
+        if kernel_initializer != "glorot_normal":
+            raise ValueError("the HIP path implements the reference's default initializer ('glorot_normal')")
+        self.filters = int(filters)
+        if self.filters <= 0:
+            raise ValueError("Filters should be > 0")
+        from .initializers import truncated_normal, _TRUNC_STD
+        rng = np.random.default_rng(seed)
+        c = self.input_dims[0][2]
+        self._weights = []
+        for i in range(self.levels - 1):
+            w3 = truncated_normal(rng, (3, 3, 2 * c, self.filters), np.sqrt(2.0 / (9 * 2 * c + 9 * self.filters)) / _TRUNC_STD)
+            w1 = truncated_normal(rng, (1, 1, self.filters, c), np.sqrt(2.0 / (self.filters + c)) / _TRUNC_STD)
+            self._weights.append({"mix.w": w3, "mix.b": np.zeros(self.filters, np.float32), "retarget.w": w1})
+
+    def get_weights(self):
+        return [dict(w) for w in self._weights]
+
+    def set_weights(self, weights):
+        if len(weights) != len(self._weights):
+            raise ValueError("expected %d weight sets" % len(self._weights))
+        new = []
+        for w, old in zip(weights, self._weights):
+            cur = {}
+            for k, v in old.items():
+                a = np.ascontiguousarray(np.asarray(w[k], np.float32))
+                if a.shape != v.shape:
+                    raise ValueError("%s has shape %s, expected %s" % (k, a.shape, v.shape))
+                cur[k] = a
+            new.append(cur)
+        self._weights = new
+
+    def __call__(self, xs):
+        torch, dev = self._torch()
+        xs = [np.ascontiguousarray(np.asarray(x, dtype=np.float32)) for x in xs]
+        if len(xs) != self.levels:
+            raise ValueError("expected %d inputs" % self.levels)
+        b = xs[0].shape[0]
+        for x, dims in zip(xs, self.input_dims):
+            if x.ndim != 4 or x.shape[0] != b or tuple(x.shape[1:]) != dims:
+                raise ValueError("expected inputs of shapes [B, *%s]" % (self.input_dims,))
+        h, w, c = self.input_dims[0]
+        if b == 0:
+            return np.zeros((0, h, w, c), np.float32)
+        ds = [torch.from_numpy(x).to(dev) for x in xs]
+        wd = [{k: torch.from_numpy(v).to(dev) for k, v in ws.items()} for ws in self._weights]
+        out = torch.empty((b, h, w, c), dtype=torch.float32, device=dev)
+        work = torch.empty(b * h * w * (4 * c + self.filters) + 64, dtype=torch.float32, device=dev)
+        n = max(self.levels - 1, 1)
+        arr = lambda key: (C.c_void_p * n)(*([d[key].data_ptr() for d in wd] or [0]))
+        ptrs = (C.c_void_p * self.levels)(*[d.data_ptr() for d in ds])
+        rc = self._lib.mvae_laplacian_merge_mix(self._device, ptrs, b, h, w, c, self.levels, self.filters, arr("mix.w"),
+                                                arr("mix.b"), arr("retarget.w"), self.min_value, self.max_value,
+                                                C.c_void_p(out.data_ptr()), C.c_void_p(work.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != _abi.MVAE_OK:
+            raise RuntimeError("mvae_laplacian_merge_mix failed (%d)" % rc)
+        torch.cuda.synchronize(dev)
+        return out.cpu().numpy()
+
+
 def laplacian_transform_split(input_dims, levels, name=None, min_value=0.0, max_value=255.0,
                               gaussian_xy_max=DEFAULT_GAUSSIAN_XY_MAX,
                               gaussian_kernel_size=DEFAULT_GAUSSIAN_KERNEL_SIZE):
@@ -134,7 +205,8 @@ def laplacian_transform_split(input_dims, levels, name=None, min_value=0.0, max_
 def laplacian_transform_merge(input_dims, levels, name=None, min_value=0.0, max_value=255.0, trainable=False,
                               filters=32, activation="relu", kernel_regularizer="l1",
                               kernel_initializer="glorot_normal"):
-    """layer_blocks.py:107-185 with trainable=False: upsample-and-add from the coarsest level, denormalise, clip."""
+    """layer_blocks.py:107-185: upsample-and-add from the coarsest level (trainable=True: with the conv mixing of
+    :147-170 in front of every Add), denormalise, clip."""
     if trainable:
-        raise NotImplementedError("laplacian_transform_merge(trainable=True) is not built (see the module docstring)")
+        return LaplacianMergeMix(input_dims, levels, name, min_value, max_value, filters, activation, kernel_initializer)
     return LaplacianMerge(input_dims, levels, name, min_value, max_value)

@@ -71,3 +71,32 @@ def laplacian_merge(levels_in, min_value=0.0, max_value=255.0):
         out = x if out is None else upsample2_bilinear(out) + x                             # :137-171
     y = (out + 1.0) * (max_value - min_value) / 2.0 + min_value                             # _denormalize, :123-131
     return np.clip(y, min_value, max_value)
+
+
+def _conv_same(x, w_hwio, b=None):
+    """keras Conv2D(strides 1, padding 'same'), kernel HWIO, odd kernel sizes (zero padding)."""
+    kh, kw, ci, co = w_hwio.shape
+    ph, pw = kh // 2, kw // 2
+    xp = np.pad(np.asarray(x, np.float64), ((0, 0), (ph, ph), (pw, pw), (0, 0)))
+    h, w = x.shape[1], x.shape[2]
+    out = np.zeros(x.shape[:3] + (co,), np.float64)
+    for a in range(kh):
+        for e in range(kw):
+            out += xp[:, a:a + h, e:e + w, :] @ np.asarray(w_hwio[a, e], np.float64)
+    return out if b is None else out + np.asarray(b, np.float64)
+
+
+def laplacian_merge_mix(levels_in, weights, min_value=0.0, max_value=255.0):
+    """layer_blocks.py:107-185 with trainable=True: weights[i] = {'mix.w' [3,3,2C,F], 'mix.b' [F], 'retarget.w'
+    [1,1,F,C]} for level i < levels - 1 (activation relu, the retargeting conv has no bias and a tanh)."""
+    out = None
+    for i in range(len(levels_in) - 1, -1, -1):
+        x = np.asarray(levels_in[i], np.float64)
+        if out is None:
+            out = x
+            continue
+        cat = np.concatenate([upsample2_bilinear(out), x], axis=-1)                         # :141-150
+        hid = np.maximum(_conv_same(cat, weights[i]["mix.w"], weights[i]["mix.b"]), 0.0)     # :151-158
+        out = np.tanh(_conv_same(hid, weights[i]["retarget.w"])) + x                         # :159-171
+    y = (out + 1.0) * (max_value - min_value) / 2.0 + min_value
+    return np.clip(y, min_value, max_value)

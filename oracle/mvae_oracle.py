@@ -532,6 +532,61 @@ class Oracle:
         return {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items() if k != "new_state"}
 
 
+# ----------------------------------------------------------------------------------------------
+# the two hot blocks as stand-alone functions with the reference's general signature (layer_blocks.py:418-462, 556-648):
+# `filters` != input channels and `squeeze_units` != channels, as the reference's own shape fixtures call them
+# (tests/test_layer_blocks.py:76-113).  The model path above is the special case filters = channels, squeeze_units = -1.
+# ----------------------------------------------------------------------------------------------
+def block_param_shapes(kind, channels, filters=32, squeeze_units=-1):
+    """Trainable tensors of one block, in the naming of param_table: kind 'se' (squeeze_excite_block on `channels`
+    inputs) or 'mnv3' (mobilenetV3_block: conv0 channels -> filters, depthwise, squeeze-excite, conv2 back)."""
+    P = OrderedDict()
+    if kind == "se":
+        su = channels if squeeze_units is None or squeeze_units <= 0 else squeeze_units       # layer_blocks.py:433-434
+        P["se.d0.w"] = (channels, su); P["se.d0.b"] = (su,)
+        P["se.bn.gamma"] = (su,); P["se.bn.beta"] = (su,)
+        P["se.d1.w"] = (su, channels); P["se.d1.b"] = (channels,)
+        return P
+    if filters <= 0:
+        raise ValueError("Filters should be > 0")                                             # layer_blocks.py:586-587
+    P["conv0.w"] = (1, 1, channels, filters); P["conv0.b"] = (filters,)
+    P["dw.w"] = (3, 3, filters, 1); P["dw.b"] = (filters,)
+    for k, v in block_param_shapes("se", filters, squeeze_units=squeeze_units).items():
+        P[k] = v
+    P["conv2.w"] = (1, 1, filters, channels); P["conv2.b"] = (channels,)
+    return P
+
+
+def squeeze_excite_block(x_nhwc, params, use_batchnorm=False, state=None, training=False):
+    """layer_blocks.py:418-462: GAP -> Dense(squeeze_units, relu) -> [BatchNorm] -> Dense(channels, hard_sigmoid) ->
+    Multiply.  params: 'se.*' tensors of block_param_shapes('se', ...)."""
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    x = t(x_nhwc).permute(0, 3, 1, 2)
+    s = F.relu(x.mean(dim=(2, 3)) @ t(params["se.d0.w"]) + t(params["se.d0.b"]))
+    if use_batchnorm:
+        if training:
+            s, _, _ = batchnorm_train(s, t(params["se.bn.gamma"]), t(params["se.bn.beta"]), SE_BN_EPS, (0,), None)
+        else:
+            mean = t(state["mean"]) if state else torch.zeros(s.shape[1], dtype=torch.float64)
+            var = t(state["var"]) if state else torch.ones(s.shape[1], dtype=torch.float64)
+            s = batchnorm_infer(s, t(params["se.bn.gamma"]), t(params["se.bn.beta"]), mean, var, SE_BN_EPS)
+    g = hard_sigmoid(s @ t(params["se.d1.w"]) + t(params["se.d1.b"]))
+    return (x * g[:, :, None, None]).permute(0, 2, 3, 1).numpy()
+
+
+def mobilenetV3_block(x_nhwc, params, training=False, state=None):
+    """layer_blocks.py:556-648 for any `filters`: conv0 1x1 (relu) -> depthwise 3x3 (relu) -> squeeze-excite with
+    BatchNorm -> conv2 1x1 back to the input's channels -> add the input."""
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    x = t(x_nhwc).permute(0, 3, 1, 2)
+    h = F.relu(conv2d_same(x, t(params["conv0.w"]), t(params["conv0.b"]), (1, 1)))
+    h = F.relu(depthwise3x3_same(h, t(params["dw.w"]), t(params["dw.b"])))
+    h = t(squeeze_excite_block(h.permute(0, 2, 3, 1).numpy(), params, use_batchnorm=True, state=state,
+                               training=training)).permute(0, 3, 1, 2)
+    out = conv2d_same(h, t(params["conv2.w"]), t(params["conv2.b"]), (1, 1)) + x
+    return out.permute(0, 2, 3, 1).numpy()
+
+
 def step_decay(initial_lr, decay_factor, step_size, epoch):
     """schedule.py:17-19."""
     return initial_lr * (decay_factor ** np.floor(epoch / step_size))

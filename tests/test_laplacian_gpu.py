@@ -53,3 +53,24 @@ def test_value_range_and_errors():
     from mvae import layer_blocks as lb
     with pytest.raises(ValueError):
         lb.laplacian_transform_split(input_dims=(30, 32, 3), levels=3)
+
+
+@pytest.mark.parametrize("dims,levels,batch,filters", [((32, 32, 3), 3, 6, 32), ((16, 24, 1), 2, 3, 8)])
+def test_trainable_merge_forward_matches_the_oracle(dims, levels, batch, filters):
+    """laplacian_transform_merge(trainable=True) (layer_blocks.py:141-171): shapes as the reference's merge fixture
+    (tests/test_layer_blocks.py:135-152), values against the oracle with the model's own and with perturbed weights."""
+    from mvae import layer_blocks as lb
+    shapes = [(dims[0] >> i, dims[1] >> i, dims[2]) for i in range(levels)]
+    model = lb.laplacian_transform_merge(input_dims=shapes, levels=levels, trainable=True, filters=filters)
+    rng = np.random.default_rng(5)
+    bands = [rng.uniform(-1.0, 1.0, (batch,) + s).astype(np.float32) for s in shapes]
+    w = model.get_weights()
+    assert len(w) == levels - 1 and w[0]["mix.w"].shape == (3, 3, 2 * dims[2], filters) and w[0]["retarget.w"].shape == (1, 1, filters, dims[2])
+    for scale in (1.0, 3.0):
+        ws = [{k: (v * scale + (0.1 if k == "mix.b" else 0.0)).astype(np.float32) for k, v in d.items()} for d in w]
+        model.set_weights(ws)
+        got = model(bands)
+        assert got.shape == (batch,) + dims and got.min() >= 0.0 and got.max() <= 255.0
+        assert np.abs(got - lo.laplacian_merge_mix(bands, ws)).max() <= 255.0 * 5e-6
+    with pytest.raises(ValueError):
+        lb.laplacian_transform_merge(input_dims=shapes, levels=levels, trainable=True, activation="elu")

@@ -157,3 +157,45 @@ def test_kink_mask_override_is_the_identity_on_the_oracles_own_active_sets():
     res3, G3 = o.loss_and_grads(*args)
     assert o.kink_report()["flips"] == 1 and o.kink_report()["max_abs_at_flip"] > 0
     assert any(not np.array_equal(G[k], G3[k]) for k in G)
+
+
+def _block_params(kind, channels, filters=32, squeeze_units=-1, seed=0):
+    from oracle.mvae_oracle import block_param_shapes
+    rng = np.random.default_rng(seed)
+    return {k: (0.3 * rng.standard_normal(shp)) for k, shp in block_param_shapes(kind, channels, filters, squeeze_units).items()}
+
+
+def test_reference_shape_fixtures_of_the_hot_blocks():
+    """tests/test_layer_blocks.py:76-113 of the reference: mobilenetV3_block(x, 32) and squeeze_excite_block(x, 32) on a
+    (3, 256, 256, 3) input return (3, 256, 256, 3) -- filters / squeeze_units differ from the 3 input channels."""
+    from oracle.mvae_oracle import mobilenetV3_block, squeeze_excite_block, block_param_shapes
+    x = np.zeros((3, 256, 256, 3))
+    p = _block_params("mnv3", 3, filters=32)
+    assert p["conv0.w"].shape == (1, 1, 3, 32) and p["se.d0.w"].shape == (32, 32) and p["conv2.w"].shape == (1, 1, 32, 3)
+    y = mobilenetV3_block(x, p)
+    assert y.shape == (3, 256, 256, 3)
+    ps = _block_params("se", 3, squeeze_units=32)
+    assert ps["se.d0.w"].shape == (3, 32) and ps["se.d1.w"].shape == (32, 3)
+    z = squeeze_excite_block(x, ps)
+    assert z.shape == (3, 256, 256, 3)
+    assert block_param_shapes("se", 3, squeeze_units=-1)["se.d0.w"] == (3, 3)           # layer_blocks.py:433-434
+    with pytest.raises(ValueError):
+        block_param_shapes("mnv3", 3, filters=0)                                          # layer_blocks.py:586-587
+
+
+def test_general_block_equals_the_model_path_when_filters_equal_channels():
+    """The stand-alone block with filters = channels, squeeze_units = -1 is what Oracle.mnv3 computes inside the model."""
+    import torch
+    from oracle.mvae_oracle import Oracle, mobilenetV3_block
+    from tests.common import oracle_config
+    c = 8
+    p = _block_params("mnv3", c, filters=c, seed=3)
+    x = np.random.default_rng(4).standard_normal((2, 6, 5, c))
+    st = {"mean": 0.1 * np.arange(c), "var": 1.0 + 0.05 * np.arange(c)}
+    y = mobilenetV3_block(x, p, training=False, state=st)
+    o = Oracle(oracle_config("tiny"))
+    T = {"b." + k: torch.as_tensor(v) for k, v in p.items()}
+    S = {"b.se.bn.mean": torch.as_tensor(st["mean"]), "b.se.bn.var": torch.as_tensor(st["var"])}
+    with torch.no_grad():
+        ref = o.mnv3(torch.as_tensor(x).permute(0, 3, 1, 2), T, "b", S, False, None, {}, None).permute(0, 2, 3, 1).numpy()
+    assert np.allclose(y, ref, rtol=1e-12, atol=1e-12)
