@@ -250,6 +250,10 @@ def main():
             except (OSError, ValueError):
                 continue
             t = pmc.get("mvae::" + dom, pmc.get(dom, {})).get("hbm_bytes_per_launch")
+            if t is None:          # a tag that covers several template instances (k16_pw): launch-weighted mean of them
+                fam = [v for k, v in pmc.items() if k.startswith("mvae::" + dom.split("<")[0] + "<")]
+                if fam and "<" not in dom:
+                    t = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam) / sum(v["launches"] for v in fam)
             if t is not None and (cand.startswith("round2") or args.workload == "c32nb"):
                 traffic, traffic_source = t, "profiles/" + cand + " (separate rocprofv3 --pmc passes, not this run)"
                 break

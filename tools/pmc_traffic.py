@@ -5,7 +5,7 @@ streaming reads by exactly 2x, WRITE_SIZE is exact.  Writes profiles/<out>.json 
 import collections, csv, glob, json, sys
 
 def load(d, counter):
-    f = glob.glob(d + '/*/*_counter_collection.csv')[0]
+    f = (glob.glob(d + '/*/*_counter_collection.csv') + glob.glob(d + '/*_counter_collection.csv'))[0]
     tot, n = collections.defaultdict(float), collections.Counter()
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
