@@ -126,6 +126,12 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream);
  * gradient part of the reduce arena (regularisers are added by mvae_apply_adagrad).  What
  * keras.Model.fit derives by autodiff from compile()'s vae_loss (multiscale_vae.py:491-504). */
 int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream);
+/* The same pass in two halves, for data-parallel callers that overlap the gradient exchange with the backward pass:
+ * phase 0 = loss, decoder halves and the Dense-layer gradients -- after it the leading mvae_reduce_split() floats of the
+ * reduce arena (the Dense weights: 95 % of the gradient bytes of the 256x256 configuration) are final and may be
+ * all-reduced while phase 1 (encoder halves, conv_base, gradient-slot fold) runs; then the rest of the arena. */
+int mvae_backward_phase(mvae_handle* h, int32_t phase, float r_factor, float kl_factor, void* stream);
+int64_t mvae_reduce_split(const mvae_handle* h);
 /* g = grad_scale * g + d(reg)/dw ; per-variable clipnorm ; Adagrad (a0 = 0.1 set by the host) ;
  * BN moving statistics update from the (reduced) batch statistics (multiscale_vae.py:497-499). */
 int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_scale, void* stream);

@@ -526,7 +526,8 @@ static bool run_dw_fwd_gap(const T* in, const float* w, const float* b, T* out, 
   if (!dw_geom(H, W, C, &g, &lds) || (H % 4) != 0) return false;
   // row segments until enough work items exist (bf16: ~1024 = four blocks per CU by LDS, half the bytes per block in
   // flight; f32: 512, the launch shape the 32x32 headline configuration was tuned on); every segment re-reads two halo rows
-  const int64_t target = sizeof(T) == 2 ? 1024 : 512;
+  static const int fwd_items = [] { const char* e = getenv("MVAE_DW_FWD_ITEMS"); return e ? atoi(e) : 0; }();
+  const int64_t target = fwd_items > 0 ? fwd_items : (sizeof(T) == 2 ? 1024 : 512);
   int nseg = 1;
   while ((int64_t)B * g.strips * nseg < target && (H / (nseg * 2)) % 4 == 0 && H / (nseg * 2) >= 8) nseg *= 2;
   if ((int64_t)B * nseg > 65535) return false;
@@ -574,8 +575,10 @@ static bool run_dw_bwd_fused(const T* dt2, const T* t1, const T* t0, const float
   // halo rows of re-reads and one exposed prologue: 1024 items measured 82 us against 76 us at B = 512, 32x32x64); the
   // kernel needs an even number of rows per segment
   if (H % 2) return false;
+  static const int bwd_items = [] { const char* e = getenv("MVAE_DW_BWD_ITEMS"); return e ? atoi(e) : 0; }();
+  const int64_t btarget = bwd_items > 0 ? bwd_items : 512;
   int nseg = 1;
-  while ((int64_t)B * g.strips * nseg < 512 && (H / (nseg * 2)) % 2 == 0 && H / (nseg * 2) >= 4) nseg *= 2;
+  while ((int64_t)B * g.strips * nseg < btarget && (H / (nseg * 2)) % 2 == 0 && H / (nseg * 2) >= 4) nseg *= 2;
   const int RS = H / nseg;
   int64_t work = (int64_t)B * nseg;
   int gy = (int)(work < kDwMaxBlocks / g.strips ? work : kDwMaxBlocks / g.strips);

@@ -93,6 +93,7 @@ struct Scale {
   int lru[4] = {0, 0, 0, 0}, tick = 0;
   int cmax = 0;
   float *dg, *dgap, *ds1, *dv, *dz, *dmu, *dlv, *dw_part;
+  float* d_mid = nullptr;                   // gradient at the encoder output between the two backward phases
 };
 
 }  // namespace
@@ -104,9 +105,11 @@ struct mvae_handle {
   std::vector<StateInfo> states;
   std::map<std::string, std::pair<int64_t, int64_t>> tensors;   // name -> (workspace float offset, elems per image)
   std::map<std::string, int> tensor_dtype;                      // name -> MVAE_ACT_* (absent = float32)
+  bool phase0_done = false;                                     // mvae_backward_phase(0) ran, phase 1 may follow
   bool kernel_gap = false;                                      // a bf16 launch found no kernel for its shape
   std::vector<Scale> scales;
   int64_t P = 0, S = 0, Z = 0, MET = 0;
+  int64_t reduce_split = 0;                 // floats of the leading Dense-weight region of the gradient arena
   int64_t ws_floats = 0;
   std::vector<ChunkDesc> chunks;
   std::vector<ChunkDesc> slot_chunks;       // tensors of at most one chunk: the only ones that receive slot atomics
@@ -168,10 +171,20 @@ void same_pad(int n, int k, int s, int* out, int* before) {
   *before = total / 2;
 }
 
+// The Dense weights (mu / log_var / decoder Dense: 95 % of the gradient bytes of C256-nb) occupy the LEADING region of
+// the parameter / gradient arena: their gradients are complete half-way through the backward pass (phase 0 of
+// mvae_backward_phase), so a data-parallel caller can all-reduce [0, mvae_reduce_split) while phase 1 still runs.
+constexpr int64_t kBigElems = 65536;
+bool is_big_param(const std::string& name, int64_t elems) {
+  auto ends = [&](const char* suf) { const size_t n = strlen(suf); return name.size() >= n && name.compare(name.size() - n, n, suf) == 0; };
+  return elems >= kBigElems && (ends(".mu.w") || ends(".log_var.w") || ends(".dense.w"));
+}
+
 // ---- plan builder ---------------------------------------------------------------------------
 struct Builder {
   mvae_handle* h;
   int64_t pcur = 0, scur = 0, wcur = 0;   // parameter / state / workspace cursors (floats)
+  int64_t bcur = 0;                       // cursor of the leading "big" region (Dense weights), see build_plan
   int maxB;
 
   int64_t param(const std::string& name, std::initializer_list<int64_t> shape, int reg) {
@@ -182,9 +195,9 @@ struct Builder {
     int i = 0;
     for (int k = 0; k < 4; ++k) p.shape[k] = 1;
     for (int64_t d : shape) { p.shape[i++] = d; p.elems *= d; }
-    p.offset = pcur;
+    if (is_big_param(name, p.elems)) { p.offset = bcur; bcur = align_up(bcur + p.elems); }
+    else { p.offset = pcur; pcur = align_up(pcur + p.elems); }
     p.reg = reg;
-    pcur = align_up(pcur + p.elems);
     h->params.push_back(p);
     return p.offset;
   }
@@ -293,6 +306,25 @@ int build_plan(mvae_handle* h) {
   Builder b{h};
   b.maxB = c.max_batch;
   const int L = c.levels, C = c.input_c;
+  {   // size of the leading Dense-weight region: K of every scale from the encoder's shape walk
+    int64_t D = 0;
+    int H0 = c.input_h, W0 = c.input_w;
+    for (int s = 0; s < L; ++s) {
+      int hh = H0, ww = W0, ch = kConvBaseFilters;
+      for (int i = 0; i < c.enc_n; ++i)
+        if (c.enc_sh[i] != 1 || c.enc_sw[i] != 1 || c.enc_filters[i] != ch) {
+          int o, pd;
+          same_pad(hh, c.enc_kh[i], c.enc_sh[i], &o, &pd); hh = o;
+          same_pad(ww, c.enc_kw[i], c.enc_sw[i], &o, &pd); ww = o;
+          ch = c.enc_filters[i];
+        }
+      const int64_t kz = (int64_t)hh * ww * ch * c.z_dims[s];
+      if (kz >= kBigElems) D += 3 * align_up(kz);
+      H0 /= 2; W0 /= 2;
+    }
+    b.pcur = D;
+    h->reduce_split = D;
+  }
 
   // fixed tables first (sizes known after the parameter pass; reserve generously afterwards) -- the
   // tables are appended at the end instead, see below.
@@ -395,6 +427,8 @@ int build_plan(mvae_handle* h) {
     sc.dz = as_ptr(b.act("", sc.z)); sc.dmu = as_ptr(b.act("", sc.z)); sc.dlv = as_ptr(b.act("", sc.z));
     H /= 2; W /= 2;
   }
+  if (b.bcur != h->reduce_split) return fail(nullptr, MVAE_E_INVALID, "internal: Dense-weight region %lld != %lld",
+                                             (long long)b.bcur, (long long)h->reduce_split);
   h->P = b.pcur; h->S = b.scur; h->Z = zoff;
   h->MET = align_up(4 + L);
   // global buffers
@@ -1086,10 +1120,11 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
   return check_launch(h, "mvae_forward");
 }
 
-int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream) {
+static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_factor, void* stream) {
   if (!h) return MVAE_E_INVALID;
   if (!h->bound || h->last_B <= 0 || !h->last_training)
     return fail(h, MVAE_E_STATE, "mvae_backward needs a preceding training-mode mvae_forward");
+  if (phase == 2 && !h->phase0_done) return fail(h, MVAE_E_STATE, "mvae_backward_phase(1) needs phase 0 first");
   const mvae_config& c = h->cfg;
   const int B = h->last_B, L = c.levels, C = c.input_c;
   hipStream_t s0 = static_cast<hipStream_t>(stream);
@@ -1097,8 +1132,11 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
   float* G = h->dr;
   // loss factors go through the device hyper-parameter block: the captured graph does not depend on their values
   launch_set_f3(h->d_hp + HP_RF_OVER_B, r_factor / (float)B, kl_factor / (float)B, 0.f, 2, s0);
+  // phase bit 1: loss, decoder halves, Dense gradients (everything that fills the leading arena region);
+  // phase bit 2: encoder halves, conv_base, gradient-slot fold.  3 = the whole pass in one graph.
   auto body = [=](hipStream_t s) {
   PreOp none{nullptr, nullptr, nullptr};
+  if (phase & 1) {
   h->ev_next = 0;
   launch_zero(G, (int64_t)(h->P), s);
   if (h->gslots.n) launch_slot_zero(h->d_slot_chunks, (int)h->slot_chunks.size(), h->gslots.base, h->gslots.stride, h->gslots.n, s);
@@ -1107,20 +1145,23 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
                   c.min_value, c.max_value, h->d_hp, s);
   for (int i = 0; i + 1 < L; ++i)
     launch_upsample_bwd(h->scales[i].dy, h->scales[i + 1].dy, B, h->scales[i + 1].H, h->scales[i + 1].W, C, s);
+  }
   fork_scales(h, s);
   hipStream_t s_main = s;
   for (int si = L - 1; si >= 0; --si) {
     hipStream_t s = scale_stream(h, si, s_main);
     profiler().cur_scale = si;
     Scale& sc = h->scales[si];
+    const int64_t M = (int64_t)B * sc.H * sc.W;
+    float* d = nullptr;
+    if (phase & 1) {
     for (int k = 0; k < 4; ++k) { sc.scratch_used[k] = false; sc.buf_pending[k] = false; }
     launch_zero(sc.dg, (int64_t)sc.dg_total * B * sc.cmax, s);   // squeeze-excite gate gradients (all slot copies)
-    const int64_t M = (int64_t)B * sc.H * sc.W;
     // ---- output conv + decoder BatchNorm
     const float* xbn = sc.dec.back().mn.out;
     ConvGeom go = geom1x1(B, sc.H, sc.W, sc.dc, C);
     PreOp bn{nullptr, sc.bn_scale, sc.bn_shift};
-    float* d = acquire(h, sc, s);
+    d = acquire(h, sc, s);
     bool fused_head;
     {
       ProfScope ps("head_bwd", 4.0 * M * (3.0 * sc.dc + 2.0 * C), 6.0 * M * sc.dc * C, s);
@@ -1220,6 +1261,10 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
       launch_gemm_nt(sc.dmu, P + sc.mu_w, d, B, (int)sc.K, sc.z, nullptr, 0, s);
       launch_gemm_nt(sc.dlv, P + sc.lv_w, d, B, (int)sc.K, sc.z, nullptr, 1, s);
     }
+    sc.d_mid = d;
+    }   // phase & 1
+    if (!(phase & 2)) continue;
+    d = sc.d_mid;
     // ---- encoder blocks, last to first
     for (int i = (int)sc.enc.size() - 1; i >= 0; --i) {
       Block& blk = sc.enc[i];
@@ -1267,17 +1312,29 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
   }
   join_scales(h, s_main);
   profiler().cur_scale = -1;
-  if (h->gslots.n)
+  if ((phase & 2) && h->gslots.n)
     launch_slot_sum(h->d_slot_chunks, (int)h->slot_chunks.size(), G, h->gslots.base, h->gslots.stride, h->gslots.n, s_main);
   };
   int rc = MVAE_OK;
   if (h->last_x == h->xin && h->last_eps == h->eps_buf)
-    rc = run_captured(h, fkey("B:%d", B), s0, body);
+    rc = run_captured(h, fkey("B%d:%d", phase, B), s0, body);
   else body(s0);
   if (rc != MVAE_OK) return rc;
+  h->phase0_done = phase == 1;
   if (h->kernel_gap) return fail(h, MVAE_E_INVALID, "mvae_backward: a bfloat16 launch found no kernel for its shape");
   return check_launch(h, "mvae_backward");
 }
+
+int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream) {
+  return backward_impl(h, 3, r_factor, kl_factor, stream);
+}
+
+int mvae_backward_phase(mvae_handle* h, int32_t phase, float r_factor, float kl_factor, void* stream) {
+  if (phase != 0 && phase != 1) return h ? fail(h, MVAE_E_INVALID, "phase must be 0 or 1") : MVAE_E_INVALID;
+  return backward_impl(h, phase == 0 ? 1 : 2, r_factor, kl_factor, stream);
+}
+
+int64_t mvae_reduce_split(const mvae_handle* h) { return h ? h->reduce_split : -1; }
 
 int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_scale, void* stream) {
   if (!h) return MVAE_E_INVALID;

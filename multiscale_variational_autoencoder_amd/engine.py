@@ -48,6 +48,7 @@ class Engine:
         self.Z = lib.mvae_latent_dim(h)
         self.R = lib.mvae_reduce_elems(h)
         self.metrics_off = lib.mvae_metrics_offset(h)
+        self.reduce_split = lib.mvae_reduce_split(h)      # leading Dense-weight region: final after backward phase 0
         self.ws_bytes = lib.mvae_workspace_bytes(h)
         self.param_table = OrderedDict()
         name = C.create_string_buffer(_abi.MVAE_NAME_CAP)
@@ -108,6 +109,7 @@ class Engine:
         # launch sequences into hipGraphs; torch ops that touch our buffers are issued under it as well
         self.stream = torch.cuda.Stream(self.device)
         self.copy_stream = None                 # pinned double-buffered H2D of datasets that do not fit in HBM
+        self.comm_stream = None                 # the early all-reduce of the Dense-weight gradients (DP overlap)
         self.dataset = None
         self.bound = True
         return self
@@ -209,6 +211,17 @@ class Engine:
     def backward(self, r_factor, kl_factor):
         self._check(self.lib.mvae_backward(self.h, float(r_factor), float(kl_factor), self._stream()))
 
+    def backward_phase(self, phase, r_factor, kl_factor):
+        self._check(self.lib.mvae_backward_phase(self.h, int(phase), float(r_factor), float(kl_factor), self._stream()))
+
+    def dp_overlap_active(self):
+        """Split the gradient exchange when the Dense-weight region is worth a collective of its own (>= 8 MB: the
+        256x256 configurations, 137 of 144 MB); MVAE_DP_OVERLAP=1 / 0 forces it on / off."""
+        env = os.environ.get("MVAE_DP_OVERLAP", "")
+        if env in ("0", "1"):
+            return env == "1" and self.reduce_split > 0
+        return self.reduce_split * 4 >= (8 << 20)
+
     def apply(self, lr, clip_norm, grad_scale=1.0):
         self._check(self.lib.mvae_apply_adagrad(self.h, float(lr), float(clip_norm if clip_norm else 0.0),
                                                 float(grad_scale), self._stream()))
@@ -226,19 +239,46 @@ class Engine:
                    force_collective=False, timing=None):
         """forward + backward (+ one RCCL all-reduce of the reduce arena when torch.distributed is up) + Adagrad.
         timing: optional list; a (start, end) pair of torch events around the all-reduce is appended."""
+        torch = self.torch
         self.forward(x, True, eps, noise, keep_mask, seed, outputs=())
-        self.backward(r_factor, kl_factor)
         scale = 1.0
-        if self.collective_active(force_collective):
-            dist = self.torch.distributed
-            with self.torch.cuda.stream(self.stream):
+        if not self.collective_active(force_collective):
+            self.backward(r_factor, kl_factor)
+        elif not self.dp_overlap_active():
+            self.backward(r_factor, kl_factor)
+            dist = torch.distributed
+            with torch.cuda.stream(self.stream):
                 if timing is not None:
-                    e0 = self.torch.cuda.Event(enable_timing=True); e1 = self.torch.cuda.Event(enable_timing=True)
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                     e0.record(self.stream)
                 dist.all_reduce(self.reduce)              # grads | BN batch statistics | metrics, one message
                 if timing is not None:
                     e1.record(self.stream)
                     timing.append((e0, e1))
+            scale = 1.0 / dist.get_world_size()
+        else:
+            # Dense-weight gradients (the leading arena region, final after phase 0) travel while the encoder halves
+            # of the backward pass still run; the rest follows as a second message.  Two collectives per step, issued in
+            # the same order on every rank.
+            dist = torch.distributed
+            D = self.reduce_split
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(self.device)
+            self.backward_phase(0, r_factor, kl_factor)
+            ready = torch.cuda.Event(); ready.record(self.stream)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ready)
+                if timing is not None:
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
+                dist.all_reduce(self.reduce[:D])
+                if timing is not None:
+                    e1.record(self.comm_stream)
+                    timing.append((e0, e1))
+            self.backward_phase(1, r_factor, kl_factor)
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(self.reduce[D:])
+            self.stream.wait_stream(self.comm_stream)
             scale = 1.0 / dist.get_world_size()
         self.apply(lr, clip_norm, scale)
 

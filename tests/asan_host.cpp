@@ -1,6 +1,7 @@
 // Host-only exercise of the C ABI glue (mvae_create / tables / validation / destroy / misuse before bind) for an
 // AddressSanitizer + UBSan build of csrc/runtime.cpp (the race / memory-error stand-in that is
 // possible here -- GPU AddressSanitizer is not available on this pool).  No HIP call is made: nothing needs a GPU.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -39,18 +40,24 @@ int main() {
       const int64_t np = mvae_param_count(h), ns = mvae_state_count(h);
       CHECK(np == 140 * sz[2] && ns > 0 && mvae_param_elems(h) > 0 && mvae_workspace_bytes(h) > 0);
       CHECK(mvae_reduce_elems(h) == mvae_param_elems(h) + mvae_state_elems(h) + (mvae_reduce_elems(h) - mvae_metrics_offset(h)));
-      int64_t prev_end = 0;
+      std::vector<std::pair<int64_t, int64_t>> slots;   // the Dense weights lead the arena (mvae_reduce_split): sort by offset
       for (int64_t i = 0; i < np; ++i) {
         char name[MVAE_NAME_CAP];
         int64_t shape[4], off; int32_t nd, reg;
         CHECK(mvae_param_info(h, i, name, sizeof(name), shape, &nd, &off, &reg) == MVAE_OK);
         int64_t n = 1; for (int k = 0; k < nd; ++k) n *= shape[k];
-        CHECK(off >= prev_end && off % 64 == 0 && n > 0 && strlen(name) > 0 && reg >= 0 && reg <= 2);
-        prev_end = off + n;
+        CHECK(off >= 0 && off % 64 == 0 && n > 0 && strlen(name) > 0 && reg >= 0 && reg <= 2);
+        slots.push_back({off, n});
         char tiny[4];                                            // truncation must stay inside the caller's buffer
         CHECK(mvae_param_info(h, i, tiny, sizeof(tiny), nullptr, nullptr, nullptr, nullptr) == MVAE_OK && strlen(tiny) <= 3);
       }
+      std::sort(slots.begin(), slots.end());
+      int64_t prev_end = 0;
+      for (auto& sl : slots) { CHECK(sl.first >= prev_end); prev_end = sl.first + sl.second; }
       CHECK(prev_end <= mvae_param_elems(h));
+      const int64_t split = mvae_reduce_split(h);               // a slot boundary: no tensor straddles the two messages
+      CHECK(split >= 0 && split % 64 == 0 && split <= mvae_param_elems(h));
+      for (auto& sl : slots) CHECK(sl.first + sl.second <= split || sl.first >= split);
       CHECK(mvae_param_info(h, np, nullptr, 0, nullptr, nullptr, nullptr, nullptr) == MVAE_E_INVALID);
       for (int64_t i = 0; i < ns; ++i) {
         char name[MVAE_NAME_CAP]; int64_t n, off;

@@ -42,9 +42,15 @@ def test_plan_tables_match_oracle(hip_lib, name):
     for k in P:
         assert eng.param_table[k]["shape"] == tuple(P[k][0]) and eng.param_table[k]["reg"] == P[k][1], k
     assert list(eng.state_table) == list(S)
-    offs = [(v["offset"], int(np.prod(v["shape"]))) for v in eng.param_table.values()]
+    # arena order: the big Dense weights first (the region [0, reduce_split) the DP path all-reduces early), then the
+    # rest in table order
+    offs = sorted((v["offset"], int(np.prod(v["shape"]))) for v in eng.param_table.values())
     for (o0, n0), (o1, _) in zip(offs, offs[1:]):
         assert o1 >= o0 + n0 and o1 % 64 == 0          # disjoint, 256-byte aligned arena slots
+    D = eng.reduce_split
+    assert 0 <= D <= eng.P and all(o + n <= D or o >= D for o, n in offs)
+    lead = {k for k, v in eng.param_table.items() if v["offset"] < D}
+    assert all(k.endswith((".mu.w", ".log_var.w", ".dense.w")) for k in lead)
     assert eng.Z == sum(oracle_config(name).z_dims)
     assert eng.R >= eng.P + eng.S + 4 + eng.levels
     big = Engine(**engine_args(name, 8))

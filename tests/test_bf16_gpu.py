@@ -141,16 +141,31 @@ def test_bf16_c256nb_parity_and_full_batch_properties():
     _check(rep, tol_grad=0.35, tol_vec=None)
     eng.close()
     B = 64
-    eng = _engine(name, B)
+    from multiscale_variational_autoencoder_amd.engine import Engine
     from multiscale_variational_autoencoder_amd.initializers import init_params
-    eng.set_params(init_params(eng.param_table, 42))
-    x = eng.to_device(np.random.default_rng(2).uniform(0, 255, (B, 256, 256, 3)))
-    vals = []
-    for step in range(6):          # same seed every step: identical noise / dropout draws, so the losses are comparable
-        eng.train_step(x, 0.003, COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"], 1.0, seed=7)
-        m = eng.metrics()
-        vals.append(1000.0 * m["r_exp"] + 10.0 * m["vae_kl_loss"])
-    assert np.isfinite(vals).all() and min(vals[-2:]) < vals[0], vals
+    x_host = np.random.default_rng(2).uniform(0, 255, (B, 256, 256, 3))
+    traj = {}
+    for dt in ("f32", "bf16"):     # same init, batch and seeds: the bf16 run has to follow the float32 run step by step
+        if dt == "bf16":
+            eng = _engine(name, B)
+        else:
+            eng = Engine(**engine_args(name, B)).bind()
+        eng.set_params(init_params(eng.param_table, 42))
+        x = eng.to_device(x_host)
+        vals = []
+        for step in range(8):      # same seed every step: identical noise / dropout draws, so the losses are comparable
+            eng.train_step(x, 0.003, COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"], 1.0, seed=7)
+            m = eng.metrics()
+            vals.append(1000.0 * m["r_exp"] + 10.0 * m["vae_kl_loss"])
+        traj[dt] = np.array(vals)
+        if dt == "f32":
+            eng.close()
+    # Adagrad's first update moves every weight by lr, so on this noise batch the objective jumps at step 1 and then
+    # descends with an oscillation, in float32 as well (tools/bf16_train_ab.py): the property is "tracks float32 within
+    # 3 % at every step and comes down from the jump", not monotone descent from step 0.
+    assert np.isfinite(traj["bf16"]).all(), traj
+    assert np.abs(traj["bf16"] / traj["f32"] - 1.0).max() <= 0.03, traj
+    assert traj["bf16"][-2:].min() < traj["bf16"][1:4].max(), traj
     out = eng.forward(x, False, seed=3, outputs=("recon",))
     r = out["recon"].cpu().numpy()
     assert np.isfinite(r).all() and r.min() >= 0.0 and r.max() <= 255.0

@@ -19,7 +19,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, name, B):
+def _worker(rank, world, port, out_dir, name, B, overlap="0"):
+    os.environ["MVAE_DP_OVERLAP"] = overlap
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -44,11 +45,12 @@ def _worker(rank, world, port, out_dir, name, B):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("name,B", [("tiny", 8), ("c32nb", 8)])
-def test_engine_dp2_matches_oracle_with_per_replica_batchnorm(tmp_path, name, B):
+@pytest.mark.parametrize("name,B,overlap", [("tiny", 8, "0"), ("c32nb", 8, "0"), ("c32nb", 8, "1")])
+def test_engine_dp2_matches_oracle_with_per_replica_batchnorm(tmp_path, name, B, overlap):
+    """overlap = "1": the two-phase backward with the Dense-weight region all-reduced while phase 1 runs."""
     import torch.multiprocessing as mp
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), name, B), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), name, B, overlap), nprocs=world, join=True)
     from oracle.mvae_oracle import Oracle
     io = make_inputs(name, B)
     orc = Oracle(oracle_config(name))

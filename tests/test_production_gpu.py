@@ -119,8 +119,10 @@ def _rccl_worker(rank, port, out_dir):
     name, B = "c32nb", 8
     io = make_inputs(name, B)
     out = {}
-    for tag, force in (("plain", False), ("rccl", True)):
+    for tag, force in (("plain", False), ("rccl", True), ("overlap", True)):
+        os.environ["MVAE_DP_OVERLAP"] = "1" if tag == "overlap" else "0"     # overlap: two-phase backward, two collectives
         eng = _engine(name, B)
+        assert eng.reduce_split > 0
         eng.set_params(io["params"]); eng.set_state(io["state"])
         d = {k: eng.to_device(io[k]) for k in ("x", "eps", "noise", "keep")}
         timing = []
@@ -131,7 +133,7 @@ def _rccl_worker(rank, port, out_dir):
         eng.sync()
         assert eng.collective_active(force) == force
         assert len(timing) == (3 if force else 0)
-        if force:
+        if tag == "rccl":
             out["allreduce_ms"] = np.array([a.elapsed_time(b) for a, b in timing])
         out[tag + "_losses"] = eng.tensor("losses", B).cpu().numpy().copy()
         for k, v in eng.get_params().items():
@@ -156,8 +158,10 @@ def test_rccl_allreduce_branch_world1(tmp_path):
     keys = [k[6:] for k in f.files if k.startswith("plain/")]
     assert keys
     lr = COMPILE["learning_rate"]
+    assert rel_err(f["plain_losses"], f["overlap_losses"]) <= 1e-5 and float(f["overlap_count"]) == 8.0
     for k in keys:      # float-atomic summation order differs from run to run: compare against the step size
         assert np.abs(f["plain/" + k] - f["rccl/" + k]).max() <= 0.05 * lr * 3, k
+        assert np.abs(f["plain/" + k] - f["overlap/" + k]).max() <= 0.05 * lr * 3, k
     assert np.isfinite(f["allreduce_ms"]).all() and (f["allreduce_ms"] > 0).all()
 
 
