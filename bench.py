@@ -196,9 +196,13 @@ def main():
     coll = None
     if collective and coll_timing:
         ar_ms = float(np.median([a.elapsed_time(b) for a, b in coll_timing]))
-        nbytes = eng.R * 4
+        overlap = eng.dp_overlap_active()
+        # overlap: the timed collective is the early message (Dense-weight gradients, on the comm stream, concurrent
+        # with backward phase 1); the second message (the rest of the arena) follows on the engine's stream
+        nbytes = (eng.reduce_split if overlap else eng.R) * 4
         n = max(world, 1)
-        coll = {"collective_bytes": nbytes, "allreduce_ms_median": ar_ms,
+        coll = {"collective_bytes": nbytes, "overlap_with_backward": overlap,
+                "second_message_bytes": (eng.R - eng.reduce_split) * 4 if overlap else 0, "allreduce_ms_median": ar_ms,
                 "algbw_GBps": nbytes / (ar_ms * 1e-3) / 1e9,
                 "busbw_GBps": nbytes / (ar_ms * 1e-3) / 1e9 * (2.0 * (n - 1) / n), "backend": rehearse or "nccl(RCCL)",
                 "world": world}
@@ -291,7 +295,10 @@ def main():
                                "train step incl. Adagrad, %s activations" % (args.workload, H, Wd, C, len(w["z_dims"]), w["z_dims"][0],
                                                             w["encoder"]["filters"], B, B * world, act),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "collective": "1 RCCL all-reduce of %d floats per step" % eng.R if collective else "none"},
+                   "collective": ("none" if not collective else
+                                  "2 RCCL all-reduces per step: %d floats (Dense-weight gradients) overlapped with the encoder "
+                                  "half of the backward pass, then %d floats" % (eng.reduce_split, eng.R - eng.reduce_split)
+                                  if eng.dp_overlap_active() else "1 RCCL all-reduce of %d floats per step" % eng.R)},
         "finite": finite,
         "timing": {"ms_per_step_median_events": med, "ms_per_step_min_events": float(per_step.min()),
                    "ms_per_step_p90_events": float(np.percentile(per_step, 90)),

@@ -132,6 +132,11 @@ int mvae_backward(mvae_handle* h, float r_factor, float kl_factor, void* stream)
  * all-reduced while phase 1 (encoder halves, conv_base, gradient-slot fold) runs; then the rest of the arena. */
 int mvae_backward_phase(mvae_handle* h, int32_t phase, float r_factor, float kl_factor, void* stream);
 int64_t mvae_reduce_split(const mvae_handle* h);
+
+/* hipGraph bookkeeping of the replayable calls: how many launch sequences are captured (one per call kind and batch), and
+ * how many calls wanted a graph but ran eagerly because the stream could not be captured (the legacy default stream).
+ * A production caller expects eager_fallbacks == 0. */
+int mvae_graph_stats(const mvae_handle* h, int32_t* captured, int32_t* eager_fallbacks);
 /* g = grad_scale * g + d(reg)/dw ; per-variable clipnorm ; Adagrad (a0 = 0.1 set by the host) ;
  * BN moving statistics update from the (reduced) batch statistics (multiscale_vae.py:497-499). */
 int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_scale, void* stream);

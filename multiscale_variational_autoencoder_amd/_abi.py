@@ -65,6 +65,7 @@ SYMBOLS = {
     "mvae_backward": (C.c_int, [_H, C.c_float, C.c_float, C.c_void_p]),
     "mvae_backward_phase": (C.c_int, [_H, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
     "mvae_reduce_split": (C.c_int64, [_H]),
+    "mvae_graph_stats": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mvae_apply_adagrad": (C.c_int, [_H, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mvae_train_step": (C.c_int, [_H, C.POINTER(MvaeStepIO), C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mvae_reg_loss": (C.c_int, [_H, C.c_void_p, C.c_void_p]),

@@ -141,6 +141,8 @@ struct mvae_handle {
   hipStream_t side[MVAE_MAX_LEVELS] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MVAE_MAX_LEVELS] = {};
   std::map<std::string, hipGraphExec_t> graphs;
+  int eager_fallbacks = 0;                 // calls that wanted a graph and ran eagerly (stream not capturable)
+  std::string eager_reason;
   std::vector<hipEvent_t> ev_pool;      // one fresh event per cross-stream edge of a backward pass
   size_t ev_next = 0;
   // last forward
@@ -799,6 +801,12 @@ hipStream_t scale_stream(mvae_handle* h, int scale, hipStream_t main) {
   if (serial_scales(h) || scale == 0) return main;
   return h->side[h->merge_side ? 1 : scale];
 }
+// TIMING DIAGNOSTIC ONLY (tools/chain_only.py): MVAE_DEBUG_ONLY_SCALE=k launches the kernels of scale k alone -- the
+// results are then garbage; it prices one scale's chain without the others beside it.
+bool debug_skip_scale(int si) {
+  static const int only = [] { const char* e = getenv("MVAE_DEBUG_ONLY_SCALE"); return e ? atoi(e) : -1; }();
+  return only >= 0 && si != only;
+}
 void fork_scales(mvae_handle* h, hipStream_t main) {
   if (serial_scales(h)) return;
   (void)hipEventRecord(h->ev_fork, main);
@@ -821,9 +829,12 @@ int run_captured(mvae_handle* h, const std::string& key, hipStream_t s, const st
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    const hipError_t eb = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (eb != hipSuccess) {
       (void)hipGetLastError();
-      body(s);                        // e.g. the legacy default stream cannot be captured: run eagerly
+      ++h->eager_fallbacks;           // e.g. the legacy default stream cannot be captured: run eagerly, and say so
+      h->eager_reason = hipGetErrorString(eb);   // (mvae_graph_stats)
+      body(s);
       return MVAE_OK;
     }
     body(s);
@@ -984,11 +995,13 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   if (const char* v = getenv("MVAE_LSB_MASK")) h->lsb_mask = atoi(v) != 0;
   if (const char* v = getenv("MVAE_MERGE_SIDE")) h->merge_side = atoi(v) != 0;   // all scales > 0 on ONE side stream
   if (h->wgrad_streams) h->use_graphs = false;
-  // scale 0 (on the caller's stream) is the long pole of every step: the other scales only fill the gaps it leaves,
-  // so their streams get the lowest priority
+  // scale 0 (on the caller's stream) is the long pole of every step and the other scales only fill the gaps it leaves,
+  // so low-priority side streams look natural -- but they buy 0.4 % on the first handle of a process and cost up to 50 %
+  // on every later one (measured, tools/chain_only.py: a second handle's side streams then share a hardware queue with
+  // its main stream and the scales serialise).  Off unless MVAE_STREAM_PRIORITY=1.
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  const bool use_prio = getenv("MVAE_STREAM_PRIORITY") ? atoi(getenv("MVAE_STREAM_PRIORITY")) != 0 : true;
+  const bool use_prio = getenv("MVAE_STREAM_PRIORITY") ? atoi(getenv("MVAE_STREAM_PRIORITY")) != 0 : false;
   for (int l = 1; l < h->cfg.levels && e == hipSuccess; ++l) {
     e = use_prio ? hipStreamCreateWithPriority(&h->side[l], hipStreamNonBlocking, prio_lo)
                  : hipStreamCreateWithFlags(&h->side[l], hipStreamNonBlocking);
@@ -1057,6 +1070,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
     fork_scales(h, s);
     PreOp none{nullptr, nullptr, nullptr};
     for (int si = L - 1; si >= 0; --si) {
+      if (debug_skip_scale(si)) continue;
       hipStream_t ss = scale_stream(h, si, s);
       profiler().cur_scale = si;
       Scale& sc = h->scales[si];
@@ -1149,6 +1163,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
   fork_scales(h, s);
   hipStream_t s_main = s;
   for (int si = L - 1; si >= 0; --si) {
+    if (debug_skip_scale(si)) continue;
     hipStream_t s = scale_stream(h, si, s_main);
     profiler().cur_scale = si;
     Scale& sc = h->scales[si];
@@ -1335,6 +1350,13 @@ int mvae_backward_phase(mvae_handle* h, int32_t phase, float r_factor, float kl_
 }
 
 int64_t mvae_reduce_split(const mvae_handle* h) { return h ? h->reduce_split : -1; }
+
+int mvae_graph_stats(const mvae_handle* h, int32_t* captured, int32_t* eager_fallbacks) {
+  if (!h) return MVAE_E_INVALID;
+  if (captured) *captured = (int32_t)h->graphs.size();
+  if (eager_fallbacks) *eager_fallbacks = h->eager_fallbacks;
+  return MVAE_OK;
+}
 
 int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_scale, void* stream) {
   if (!h) return MVAE_E_INVALID;

@@ -214,6 +214,12 @@ class Engine:
     def backward_phase(self, phase, r_factor, kl_factor):
         self._check(self.lib.mvae_backward_phase(self.h, int(phase), float(r_factor), float(kl_factor), self._stream()))
 
+    def graph_stats(self):
+        """(captured launch sequences, calls that fell back to eager launches)."""
+        cap, eager = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.mvae_graph_stats(self.h, C.byref(cap), C.byref(eager)))
+        return cap.value, eager.value
+
     def dp_overlap_active(self):
         """Split the gradient exchange when the Dense-weight region is worth a collective of its own (>= 8 MB: the
         256x256 configurations, 137 of 144 MB); MVAE_DP_OVERLAP=1 / 0 forces it on / off."""

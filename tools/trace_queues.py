@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-queue busy/gap analysis of one train step from a rocprofv3 --kernel-trace CSV."""
 import csv, glob, collections, sys
-f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv') + glob.glob(sys.argv[1] + '/*_kernel_trace.csv'))[0]
 rows = [r for r in csv.DictReader(open(f)) if 'mvae' in r['Kernel_Name']]
 for r in rows:
     r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
@@ -36,3 +36,11 @@ for r in byq[qmain]:
 print("-- busiest queue (scale 0 chain):")
 for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:24]:
     print("  %-46s n=%3d  %.3f ms  avg %.1f us" % (k, n, t / 1e6, t / n / 1e3))
+print("-- gaps > 15 us on the busiest queue (kernel before -> after, what ran elsewhere meanwhile):")
+rs = byq[qmain]
+short = lambda r: r['Kernel_Name'].split('(')[0].replace('void ', '').replace('mvae::', '')[:36]
+for i in range(len(rs) - 1):
+    g = rs[i + 1]['s'] - rs[i]['e']
+    if g > 15000:
+        other = [short(r) + "@q%s" % r['Queue_Id'] for r in step if r['Queue_Id'] != qmain and r['s'] < rs[i + 1]['s'] and r['e'] > rs[i]['e']]
+        print("  %.1f us at +%.3f ms: %s -> %s | %s" % (g / 1e3, (rs[i]['e'] - a) / 1e6, short(rs[i]), short(rs[i + 1]), ", ".join(other[:6])))
