@@ -236,6 +236,11 @@ constexpr int kDwMaxBlocks = 1024;     // partial-sum scratch: kDwMaxBlocks * 10
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
                          const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
                          int W, int C, hipStream_t s, bool bf = false);
+// bf16: that depthwise backward fused with conv0's backward pair (kernels_bf16.hip: k16_dw_bwd_conv0) -- da = dt0 . W0^T +
+// dout, dW0 += a^T dt0, db0; dt0 never stored.  C = 64, W % 32 == 0, mask in the LSB of dt2.  false = shape not covered.
+bool launch16_dw_bwd_conv0(const void* dt2, const void* t0, const float* w, const float* gate, const float* dgap,
+                           const float* W0, const void* a_in, const void* dout, void* da, float* dW, float* db, float* dW0,
+                           float* db0, GradSlots sl, int B, int H, int W, int C, hipStream_t s);
 // Dense layers around the latent (kernels_dense.hip); false = shape not covered
 bool launch_dense_mu_lv(const float* x, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
                         float* mu, float* lv, int B, int K, int Z, hipStream_t s, bool bf = false);

@@ -809,6 +809,270 @@ bool launch16_dual(const void* X, const float* W, const void* aux, const float* 
   return true;
 }
 
+// =================================================================================================
+// Depthwise backward (k_dw_bwd_ring<true, bf16_t>, kernels_dw.hip) and conv0's backward pair (k16_dual MODE 2) in ONE
+// pass: dt0, the depthwise backward's output, never goes to HBM (5 tensor passes per block element instead of 7, and
+// the ring phase is VALU-bound in bf16, so the two extra streams ride under it).  C = 64, W % 32 == 0, H even, the ReLU
+// mask of t1 in the bf16 LSB of dt2.  A strip is 32 columns: after the ring step of image row y the strip's dt0 row is a
+// 32 x 64 bf16 tile in LDS; every two rows the four waves run, on tiles (y, y + 1) and the block-input / dout tiles
+// fetched beside them,
+//     da^T[co tile][32 px] = W0^T . dt0^T (+ dout)     wave (kk = w & 1, nt = w >> 1): 4 MFMAs, 16-byte stores
+//     P[co][ci] += dt0^T a over the 64 px               wave (nt = w & 1, kt = w >> 1): 4 MFMAs from ds_read_b64_tr_b16
+// The finished da tile is stored one step late, behind the next pair's tile loads (vmcnt is one in-order queue).
+// =================================================================================================
+template <bool HALO>
+__global__ void __launch_bounds__(256, 2) k16_dw_bwd_conv0(const uint2* __restrict__ dt2, const uint2* __restrict__ t0,
+                                                           const f32x4* __restrict__ w, const f32x4* __restrict__ gate,
+                                                           const f32x4* __restrict__ dgap, const float* __restrict__ W0,
+                                                           const bf16_t* __restrict__ a_in, const bf16_t* __restrict__ dout,
+                                                           bf16_t* __restrict__ da, float* __restrict__ dW,
+                                                           float* __restrict__ db, float* __restrict__ dW0,
+                                                           float* __restrict__ db0, int H, int W, int strips, float inv_hw,
+                                                           int B, int RS, int nseg, int nslots, int64_t slot_stride) {
+  constexpr int XSP = 34, RINGB = 4 * XSP * 16 * 16, TB = 32 * 64 * 2;
+  extern __shared__ __attribute__((aligned(16))) char lds16[];
+  f32x4* ring = reinterpret_cast<f32x4*>(lds16);                       // 4 x 34 x 16 float4 of d1
+  char* tD = lds16 + RINGB;                                            // dt0 tiles of rows y2, y2 + 1
+  char* tA = tD + 2 * TB;                                              // block input tiles
+  char* tR = tA + 2 * TB;                                              // dout tiles
+  u32x4* wfl = reinterpret_cast<u32x4*>(tR + 2 * TB);                  // W0 fragments, one 16-byte slot per (fragment, lane)
+  const int x0 = blockIdx.x * 32;
+  const int c4 = threadIdx.x & 15;
+  const int xl0 = threadIdx.x >> 4, xl1 = xl0 + 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  if (wave == 0) {
+    bf16x8 wf[2][4];
+    load_wfrags<64, 64, true>(W0, r, h, wf);                           // Wm[k = co][n = ci] = W0[ci*64 + co]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wfl[(nt * 4 + kk) * 64 + lane] = __builtin_bit_cast(u32x4, wf[nt][kk]);
+  }
+#define RING16(slot, xs, c4_) ring[((slot) * XSP + (xs)) * 16 + (c4_)]
+  if (!HALO && threadIdx.x < 128) {                                    // columns 0 and 33 of the four slots: always zero
+    const int slot = threadIdx.x >> 5, side = (threadIdx.x >> 4) & 1;
+    RING16(slot, side ? 33 : 0, c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 wt[9], aw[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { wt[k] = w[k * 16 + c4]; aw[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  f32x4 ab = {0.f, 0.f, 0.f, 0.f};
+  f32x16 accw = zero16();                                              // P tile: co = 32 (wave & 1) + .., ci = 32 (wave >> 1) + r
+  float bsum = 0.f;
+  const int pnt = wave & 1, pkt = wave >> 1;                           // weight-gradient role
+  const int ykk = wave & 1, ynt = wave >> 1;                           // data-GEMM role: tile row, output-channel tile
+
+  for (int item = blockIdx.y; item < B * nseg; item += gridDim.y) {
+    const int b = item / nseg, seg = item % nseg;
+    const int ya = seg * RS, yb = min(H, ya + RS);
+    const int64_t ioff = (int64_t)b * H * W * 16;                      // 4-element offset of the image
+    constexpr int NU = HALO ? 3 : 2;
+    uint2 Fd[2][NU], T[2][2];
+    const f32x4 gg_c = gate[(int64_t)b * 16 + c4];
+    const f32x4 dg_c = dgap[(int64_t)b * 16 + c4] * inv_hw;
+    const int ybc = min(yb, H - 1);
+    auto fetch_row = [&](int y, uint2 (&rd)[NU]) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int t = threadIdx.x + 256 * u;
+        const int x = HALO ? x0 - 1 + (t >> 4) : (u == 0 ? xl0 : xl1);
+        const bool ok = HALO ? (t < XSP * 16 && x >= 0 && x < W) : true;
+        rd[u] = dt2[ok ? ioff + ((int64_t)y * W + x) * 16 + c4 : 0];
+      }
+    };
+    auto store_row = [&](int y, const uint2 (&rdr)[NU]) {              // d1 row y (+ halo) -> ring slot y & 3
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int t = HALO ? threadIdx.x + 256 * u : ((u == 0 ? xl0 : xl1) + 1) * 16 + c4;
+        const int x = x0 - 1 + (t >> 4);
+        const bool ok = HALO ? (x >= 0 && x < W) : true;
+        if (!HALO || t < XSP * 16) {
+          const f32x4 rd = unpack4(rdr[u]);
+          f32x4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned bits = __float_as_uint(rd[q]);
+            const bool on = (bits & 0x10000u) != 0u;                   // ReLU mask t1 > 0 in the bf16 LSB, cleared for the value
+            v[q] = (ok && on) ? __uint_as_float(bits & ~0x10000u) * gg_c[q] + dg_c[q] : 0.f;
+          }
+          RING16(y & 3, t >> 4, c4) = v;
+        }
+      }
+    };
+    auto fetch_t0 = [&](int y, uint2 (&tv)[2]) {
+      tv[0] = t0[ioff + ((int64_t)y * W + x0 + xl0) * 16 + c4];
+      tv[1] = t0[ioff + ((int64_t)y * W + x0 + xl1) * 16 + c4];
+    };
+    __syncthreads();                                  // previous item's ring / tile reads are done (and wfl is written)
+    fetch_row(max(ya - 1, 0), Fd[0]);
+    fetch_row(ya, Fd[1]);
+    fetch_t0(ya, T[0]);
+    fetch_t0(min(ya + 1, yb - 1), T[1]);
+    store_row(ya - 1, Fd[0]);
+    store_row(ya, Fd[1]);
+    fetch_row(min(ya + 1, ybc), Fd[1]);
+    fetch_row(min(ya + 2, ybc), Fd[0]);
+    u32x4 out0 = {0u, 0u, 0u, 0u}, out1 = out0;       // the finished da tile of the previous pair (this lane's 2 x 16 bytes)
+    int64_t out_off = 0;
+    bool pending = false;
+    for (int y2 = ya; y2 < yb; y2 += 2) {
+      // block input and dout of rows (y2, y2 + 1), columns x0 .. x0 + 31: four 4 KB runs, thread t takes 16-byte chunk t of
+      // each (chunk = pixel * 8 + channel chunk)
+      const int64_t px0 = (int64_t)b * H * W + (int64_t)y2 * W + x0;   // pixel index of (y2, x0)
+      const u32x4 la0 = reinterpret_cast<const u32x4*>(a_in + px0 * 64)[threadIdx.x];
+      const u32x4 la1 = reinterpret_cast<const u32x4*>(a_in + (px0 + W) * 64)[threadIdx.x];
+      const u32x4 lr0 = reinterpret_cast<const u32x4*>(dout + px0 * 64)[threadIdx.x];
+      const u32x4 lr1 = reinterpret_cast<const u32x4*>(dout + (px0 + W) * 64)[threadIdx.x];
+      if (pending) {
+        *reinterpret_cast<u32x4*>(da + out_off) = out0;
+        *reinterpret_cast<u32x4*>(da + out_off + 16) = out1;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int y = y2 + kk;
+        store_row(y + 1, Fd[(kk + 1) & 1]);
+        fetch_row(min(y + 3, ybc), Fd[(kk + 1) & 1]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int xl = k == 0 ? xl0 : xl1;
+          const f32x4 tvk = unpack4(T[kk][k]);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const int yy = y - a + 1;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              const f32x4 sv = RING16(yy & 3, xl + 2 - e, c4);
+              acc += wt[a * 3 + e] * sv;
+              aw[a * 3 + e] += tvk * sv;
+            }
+          }
+          ab += RING16(y & 3, xl + 1, c4);
+          f32x4 rv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rv[q] = tvk[q] > 0.f ? acc[q] : 0.f;
+          *reinterpret_cast<uint2*>(tD + kk * TB + tile_off<64>(xl, c4 >> 1) + (c4 & 1) * 8) = pack4(rv);
+        }
+        fetch_t0(min(y + 2, yb - 1), T[kk]);
+      }
+      {
+        const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;
+        *reinterpret_cast<u32x4*>(tA + tile_off<64>(row, ch)) = la0;
+        *reinterpret_cast<u32x4*>(tA + TB + tile_off<64>(row, ch)) = la1;
+        *reinterpret_cast<u32x4*>(tR + tile_off<64>(row, ch)) = lr0;
+        *reinterpret_cast<u32x4*>(tR + TB + tile_off<64>(row, ch)) = lr1;
+      }
+      __syncthreads();                                // all six tiles complete
+      // ---- P[co][ci] += dt0^T a over both rows
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          const bf16x8 fa = frag_cols<64>(tD + kk * TB, lane, pnt, sidx);
+          const bf16x8 fb = frag_cols<64>(tA + kk * TB, lane, pkt, sidx);
+          if (pkt == 0) bsum = frag_sum(fa, bsum);
+          accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, accw, 0, 0, 0);
+        }
+      // ---- da tile: row y2 + ykk, output channels 32 ynt ..
+      f32x16 acc = zero16();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wfl[(ynt * 4 + kk) * 64 + lane]),
+                                                      frag_rows<64>(tD + ykk * TB, r, h, kk), acc, 0, 0, 0);
+      uint2 pk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = ynt * 32 + 8 * q + 4 * h;
+        f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        v += unpack4(*reinterpret_cast<const uint2*>(tR + ykk * TB + tile_off<64>(r, c0 >> 3) + (c0 & 7) * 2));
+        pk[q] = pack4(v);
+      }
+      {
+        auto s0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+        out0 = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        auto s2 = __builtin_amdgcn_permlane32_swap(pk[2].x, pk[3].x, false, false);
+        auto s3 = __builtin_amdgcn_permlane32_swap(pk[2].y, pk[3].y, false, false);
+        out1 = u32x4{s2[0], s3[0], s2[1], s3[1]};
+      }
+      out_off = (px0 + (int64_t)ykk * W + r) * 64 + ynt * 32 + 8 * h;
+      pending = true;
+    }
+    if (pending) {
+      *reinterpret_cast<u32x4*>(da + out_off) = out0;
+      *reinterpret_cast<u32x4*>(da + out_off + 16) = out1;
+    }
+  }
+  // ---- depthwise weight / bias gradients: block reduction as in k_dw_bwd_ring
+  __syncthreads();
+  f32x4* red = ring;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    f32x4 v = k < 9 ? aw[k < 9 ? k : 0] : ab;
+    for (int off = 16; off < 64; off <<= 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += __shfl_xor(v[q], off, 64);
+    }
+    if (lane < 16) red[(wave * 10 + k) * 16 + lane] = v;
+  }
+  __syncthreads();
+  const int64_t slot = (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) % nslots) * slot_stride;
+  for (int idx = threadIdx.x; idx < 10 * 16 * 4; idx += 256) {
+    const int q = idx & 3, cc = (idx >> 2) % 16, k = (idx >> 2) / 16;
+    float t = 0.f;
+    for (int wv = 0; wv < 4; ++wv) t += red[(wv * 10 + k) * 16 + cc][q];
+    atomicAdd((k < 9 ? dW + slot + (int64_t)k * 64 : db + slot) + cc * 4 + q, t);
+  }
+  // ---- conv0 weight gradient: the four P tiles through LDS (dW0[ci][co] row-major), one coalesced atomic set per block
+  __syncthreads();
+  float* redw = reinterpret_cast<float*>(lds16);
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int co = pnt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, ci = pkt * 32 + r;
+    redw[ci * 64 + co] = accw[reg];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) atomicAdd(&dW0[slot + idx], redw[idx]);
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (pkt == 0 && h == 0 && db0 != nullptr) atomicAdd(&db0[slot + pnt * 32 + r], bsum);
+#undef RING16
+}
+
+// dt2 (bf16, ReLU mask in the LSB) -> da, dW_dw, db_dw, dW0, db0.  false = shape not covered (the caller then runs
+// launch_dw_bwd_fused and launch16_dual).
+bool launch16_dw_bwd_conv0(const void* dt2, const void* t0, const float* w, const float* gate, const float* dgap,
+                           const float* W0, const void* a_in, const void* dout, void* da, float* dW, float* db, float* dW0,
+                           float* db0, GradSlots sl, int B, int H, int W, int C, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("MVAE_FUSE_DW_CONV0"); return e ? atoi(e) != 0 : true; }();
+  if (!on || C != 64 || W % 32 != 0 || H % 2 != 0 || H < 4) return false;
+  const int strips = W / 32;
+  int nseg = 1;
+  while ((int64_t)B * strips * nseg < 512 && (H / (nseg * 2)) % 2 == 0 && H / (nseg * 2) >= 4) nseg *= 2;
+  const int RS = H / nseg;
+  const int64_t work = (int64_t)B * nseg;
+  const int gy = (int)(work < kDwMaxBlocks / strips ? work : kDwMaxBlocks / strips);
+  if (gy < 1) return false;
+  const size_t lds = (size_t)4 * 34 * 16 * 16 + 6 * 4096 + 8 * 64 * 16;
+  static const bool attr = [] {
+    return hipFuncSetAttribute((const void*)k16_dw_bwd_conv0<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+           hipFuncSetAttribute((const void*)k16_dw_bwd_conv0<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+  }();
+  if (!attr) return false;
+  const double M = (double)B * H * W;
+  ProfScope ps("k16_dw_bwd_conv0", 2.0 * M * C * 5, (40.0 + 4.0 * C) * M * C, s);
+#define MVAE_DWC16(HALO)                                                                                               \
+  hipLaunchKernelGGL(k16_dw_bwd_conv0<HALO>, dim3(strips, gy), dim3(256), lds, s, (const uint2*)dt2, (const uint2*)t0, \
+                     (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, W0, (const bf16_t*)a_in,                 \
+                     (const bf16_t*)dout, (bf16_t*)da, sl.at(dW), sl.at(db), sl.at(dW0), sl.at(db0), H, W, strips,     \
+                     1.0f / (float)(H * W), B, RS, nseg, sl.count(), sl.stride)
+  if (strips > 1) MVAE_DWC16(true); else MVAE_DWC16(false);
+#undef MVAE_DWC16
+  return true;
+}
+
 // k x k convolution (F-form: in = big) / transposed convolution (T-form: in = small).  false = shape not covered.
 bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g,
                    hipStream_t s) {

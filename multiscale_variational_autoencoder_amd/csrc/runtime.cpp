@@ -648,6 +648,14 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
                                  sc.dgap, G + m.sw1, G + m.sb1, G + m.gam, G + m.bet, G + m.sw0, G + m.sb0, m.se_part, B, c,
                                  h->gslots, m.dg_slots, dg_stride, s));
     float* bufC16 = acquire(h, sc, s);
+    // depthwise backward and conv0's pair in one pass where the shape allows (dt0 is then never stored)
+    if (h->lsb_mask && !dw_uses_img(true, true, B, m.H, m.W, c) &&
+        launch16_dw_bwd_conv0(bufB, m.t0, P + m.wd, m.g, sc.dgap, P + m.w0, x, dout, bufC16, G + m.wd, G + m.bd, G + m.w0,
+                              G + m.b0, h->gslots, B, m.H, m.W, c, s)) {
+      release(sc, bufB);
+      release(sc, dout);
+      return bufC16;
+    }
     {
       ProfScope ps(dw_uses_img(true, h->lsb_mask, B, m.H, m.W, c) ? "k_dw_bwd_img" : (h->lsb_mask ? "k_dw_bwd_ring<true>" : "k_dw_bwd_ring<false>"),
                    (h->lsb_mask ? 6.0 : 8.0) * B * HW * c, 40.0 * B * HW * c, s);
@@ -1162,14 +1170,15 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
   }
   fork_scales(h, s);
   hipStream_t s_main = s;
-  for (int si = L - 1; si >= 0; --si) {
-    if (debug_skip_scale(si)) continue;
+  // One scale's backward: `bits` & 1 = decoder half (ends with sc.d_mid), & 2 = encoder half.
+  auto scale_half = [&](int si, int bits) {
+    if (debug_skip_scale(si)) return;
     hipStream_t s = scale_stream(h, si, s_main);
     profiler().cur_scale = si;
     Scale& sc = h->scales[si];
     const int64_t M = (int64_t)B * sc.H * sc.W;
     float* d = nullptr;
-    if (phase & 1) {
+    if (bits & 1) {
     for (int k = 0; k < 4; ++k) { sc.scratch_used[k] = false; sc.buf_pending[k] = false; }
     launch_zero(sc.dg, (int64_t)sc.dg_total * B * sc.cmax, s);   // squeeze-excite gate gradients (all slot copies)
     // ---- output conv + decoder BatchNorm
@@ -1277,8 +1286,8 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
       launch_gemm_nt(sc.dlv, P + sc.lv_w, d, B, (int)sc.K, sc.z, nullptr, 1, s);
     }
     sc.d_mid = d;
-    }   // phase & 1
-    if (!(phase & 2)) continue;
+    }   // decoder half
+    if (!(bits & 2)) return;
     d = sc.d_mid;
     // ---- encoder blocks, last to first
     for (int i = (int)sc.enc.size() - 1; i >= 0; --i) {
@@ -1324,7 +1333,11 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
       launch_conv_wgrad(sc.band, d, G + sc.cb_w, G + sc.cb_b, g, none, h->gslots, s);
     }
     release(sc, d);
-  }
+  };
+  // (Holding the smaller scales back until scale 0 reaches its MFMA-bound 5x5 convolutions, so that their HBM-bound work
+  // would fill those windows, was measured: 5.88 .. 6.05 ms against 5.92 -- their chains are latency-bound and only move
+  // the contention.  They start at the fork.)
+  for (int si = L - 1; si >= 0; --si) scale_half(si, phase);
   join_scales(h, s_main);
   profiler().cur_scale = -1;
   if ((phase & 2) && h->gslots.n)
