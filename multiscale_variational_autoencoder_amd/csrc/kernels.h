@@ -236,6 +236,10 @@ constexpr int kDwMaxBlocks = 1024;     // partial-sum scratch: kDwMaxBlocks * 10
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
                          const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
                          int W, int C, hipStream_t s, bool bf = false);
+// bf16: conv2 of one MobileNetV3 block chained with conv0 of the next (k16_pw_chain); false = shape not covered
+bool launch16_pw_chain(const void* in, const float* w, const float* bias, const float* gate, const void* residual, void* out,
+                       const float* w2, const float* bias2, void* out2, int64_t M, int64_t rows_per_image, int C,
+                       hipStream_t s);
 // bf16: that depthwise backward fused with conv0's backward pair (kernels_bf16.hip: k16_dw_bwd_conv0) -- da = dt0 . W0^T +
 // dout, dW0 += a^T dt0, db0; dt0 never stored.  C = 64, W % 32 == 0, mask in the LSB of dt2.  false = shape not covered.
 bool launch16_dw_bwd_conv0(const void* dt2, const void* t0, const float* w, const float* gate, const float* dgap,

@@ -274,6 +274,138 @@ __global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, cons
 }
 
 // =================================================================================================
+// conv2 of one MobileNetV3 block and conv0 of the NEXT block in one launch (64 -> 64 both, layer_blocks.py:625-641 then
+// :594-602 of the following block):   Y = (X * gate) . W + bias + residual  (stored: it is the next block's residual and a
+// saved tensor)  and  Y2 = relu(Y . W2 + bias2)  from the SAME registers -- the 16-byte chunks lane (r, h) has just
+// formed for the store of pixel r (channels 32 nt + 16 p + 8 h ..) are exactly the B-operand fragments kk = 2 nt + p of the
+// second product, so Y is not read back (one tensor pass less per block).  The second product sees the bf16-rounded Y,
+// as the separate launch would.  W2 fragments and bias2 sit in LDS (registers: 208 + 16).
+// =================================================================================================
+__global__ void __launch_bounds__(256) k16_pw_chain(const bf16_t* __restrict__ X, const float* __restrict__ W,
+                                                    const float* __restrict__ bias, const float* __restrict__ gate,
+                                                    const bf16_t* __restrict__ res, bf16_t* __restrict__ Y,
+                                                    const float* __restrict__ W2, const float* __restrict__ bias2,
+                                                    bf16_t* __restrict__ Y2, int64_t ntiles, int64_t rows_per_image) {
+  constexpr int K = 64, N = 64, TB = 32 * K * 2, RB = 32 * N * 2;
+  __shared__ __attribute__((aligned(16))) char lds[4 * (TB + RB) + 8 * 64 * 16 + 64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  char* tile = lds + wave * (TB + RB);
+  char* rtile = tile + TB;
+  u32x4* wfl2 = reinterpret_cast<u32x4*>(lds + 4 * (TB + RB));
+  float* b2s = reinterpret_cast<float*>(lds + 4 * (TB + RB) + 8 * 64 * 16);
+  bf16x8 wf[2][4];
+  load_wfrags<K, N, false>(W, r, h, wf);
+  if (wave == 0) {
+    bf16x8 w2[2][4];
+    load_wfrags<64, 64, false>(W2, r, h, w2);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wfl2[(nt * 4 + kk) * 64 + lane] = __builtin_bit_cast(u32x4, w2[nt][kk]);
+    b2s[lane] = bias2 ? bias2[lane] : 0.f;
+  }
+  f32x4 bz[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bz[nt][q] = bias ? *reinterpret_cast<const f32x4*>(bias + nt * 32 + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  TileRegs<K> cur, nxt;
+  TileRegs<N> rcur, rnxt;
+  f32x4 gc0 = {1.f, 1.f, 1.f, 1.f}, gc1 = gc0, gn0 = gc0, gn1 = gc0;
+  auto gate_load = [&](int64_t tl, f32x4& a, f32x4& b) {
+    const f32x4* gp = reinterpret_cast<const f32x4*>(gate + (tl * 32 / rows_per_image) * K + (lane % (K / 8)) * 8);
+    a = gp[0]; b = gp[1];
+  };
+  if (t < ntiles) {
+    tile_load<K>(X, t * 32, lane, cur);
+    tile_load<N>(res, t * 32, lane, rcur);
+    gate_load(t, gc0, gc1);
+  }
+  for (; t < ntiles; t += stride) {
+    const int64_t row0 = t * 32;
+    const int64_t tn = t + stride < ntiles ? t + stride : t;
+    tile_load<K>(X, tn * 32, lane, nxt);
+    tile_load<N>(res, tn * 32, lane, rnxt);
+    gate_load(tn, gn0, gn1);
+#pragma unroll
+    for (int j = 0; j < K / 16; ++j) {
+      const u32x4 u = cur.v[j];
+      float v[8] = {bf16_lo(u[0]) * gc0[0], bf16_hi(u[0]) * gc0[1], bf16_lo(u[1]) * gc0[2], bf16_hi(u[1]) * gc0[3],
+                    bf16_lo(u[2]) * gc1[0], bf16_hi(u[2]) * gc1[1], bf16_lo(u[3]) * gc1[2], bf16_hi(u[3]) * gc1[3]};
+      cur.v[j] = __builtin_bit_cast(u32x4, frag_of(v));
+    }
+    WAVE_LDS_SYNC16();
+    tile_store_lds<K>(tile, lane, cur);
+    tile_store_lds<N>(rtile, lane, rcur);
+    WAVE_LDS_SYNC16();
+    f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 xb = frag_rows<K>(tile, r, h, kk);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][kk], xb, acc[nt], 0, 0, 0);
+    }
+    // ---- Y = acc + bias + residual -> bf16; o[2 nt + p] = channels 32 nt + 16 p + 8 h .. + 7 of pixel row0 + r
+    const int64_t rowoff = (row0 + r) * N;
+    u32x4 o[4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      uint2 pk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = nt * 32 + 8 * q + 4 * h;
+        f32x4 v = {acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
+        v += bz[nt][q];
+        v += unpack4(*reinterpret_cast<const uint2*>(rtile + tile_off<N>(r, c0 >> 3) + (c0 & 7) * 2));
+        pk[q] = pack4(v);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        uint2 a = pk[2 * p], b = pk[2 * p + 1];
+        auto s0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+        o[2 * nt + p] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        *reinterpret_cast<u32x4*>(Y + rowoff + nt * 32 + 16 * p + 8 * h) = o[2 * nt + p];
+      }
+    }
+    // ---- Y2 = relu(Y . W2 + bias2): the chunks above are the B fragments
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[nt] = zero16();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wfl2[(nt * 4 + kk) * 64 + lane]), as_frag(o[kk]), acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      uint2 pk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = nt * 32 + 8 * q + 4 * h;
+        f32x4 v = {acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
+        v += *reinterpret_cast<const f32x4*>(b2s + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        pk[q] = pack4(v);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        uint2 a = pk[2 * p], b = pk[2 * p + 1];
+        auto s0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+        *reinterpret_cast<u32x4*>(Y2 + rowoff + nt * 32 + 16 * p + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+    }
+    cur = nxt; rcur = rnxt; gc0 = gn0; gc1 = gn1;
+  }
+}
+
+// =================================================================================================
 // Backward pair of a 1x1 C -> C convolution of the MobileNetV3 block in ONE pass over (X, aux) (layer_blocks.py:594-641
 // inverted; the f32 counterpart is k_gemm_dual):
 //     Y[M,C]  = X . W^T (+ residual)                       W = Conv2D kernel [ci][co]
@@ -781,6 +913,21 @@ bool launch16_pw(bool transposed, const void* in, const float* w, const float* b
 #undef MVAE_PW1
 #undef MVAE_PW
   return false;
+}
+
+// conv2 of a block chained with conv0 of the next one (k16_pw_chain; both 64 -> 64).  false = shape not covered.
+bool launch16_pw_chain(const void* in, const float* w, const float* bias, const float* gate, const void* residual, void* out,
+                       const float* w2, const float* bias2, void* out2, int64_t M, int64_t rows_per_image, int C,
+                       hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("MVAE_FUSE_PW_CHAIN"); return e ? atoi(e) != 0 : true; }();
+  if (!on || C != 64 || M % 32 != 0 || M <= 0 || rows_per_image % 32 != 0 || !gate || !residual) return false;
+  const int64_t ntiles = M / 32;
+  const int64_t nblk = (ntiles + 3) / 4;
+  const int grid = (int)(nblk < 4 * cus16() ? nblk : 4 * cus16());
+  ProfScope ps("k16_pw_chain", 2.0 * M * C * 4, 4.0 * M * C * C, s);
+  hipLaunchKernelGGL(k16_pw_chain, dim3(grid), dim3(256), 0, s, (const bf16_t*)in, w, bias, gate, (const bf16_t*)residual,
+                     (bf16_t*)out, w2, bias2, (bf16_t*)out2, ntiles, rows_per_image);
+  return true;
 }
 
 // MobileNetV3 backward pair (see k16_dual).  false = shape not covered.

@@ -578,7 +578,10 @@ ConvGeom geom1x1(int B, int H, int W, int ci, int co) {
 // a bf16 launch must find a kernel: there is no silent fallback to another precision
 inline void need16(mvae_handle* h, bool ok) { if (!ok) h->kernel_gap = true; }
 
-void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipStream_t s, bool bf) {
+// chain: the NEXT block of the same shape (no convolution in between), whose conv0 this block's conv2 launch also
+// computes (bf16, 64 channels); conv0_done: this block's conv0 was computed that way.  Returns whether it chained.
+bool mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipStream_t s, bool bf, MN* chain = nullptr,
+                bool conv0_done = false) {
   const float* P = h->dp;
   float* stats = h->dr + h->P;
   const int c = m.c;
@@ -586,7 +589,7 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
   ConvGeom g = geom1x1(B, m.H, m.W, c, c);
   PreOp none{nullptr, nullptr, nullptr};
   if (bf) {
-    need16(h, launch16_pw(false, x, P + m.w0, P + m.b0, nullptr, nullptr, m.t0, M, HW, c, c, ACT_RELU, s));
+    if (!conv0_done) need16(h, launch16_pw(false, x, P + m.w0, P + m.b0, nullptr, nullptr, m.t0, M, HW, c, c, ACT_RELU, s));
   } else {
     bool tiled0;
     {
@@ -615,8 +618,11 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
     launch_gemm_nn(m.s1, P + m.sw1, P + m.sb1, m.g, m.ulin, B, c, c, ACT_HSIG, s);
   }
   if (bf) {
+    if (chain && !m.out_f32 && chain->c == c && chain->H == m.H && chain->W == m.W &&
+        launch16_pw_chain(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, P + chain->w0, P + chain->b0, chain->t0, M, HW, c, s))
+      return true;
     need16(h, launch16_pw(false, m.t1, P + m.w2, P + m.b2, m.g, x, m.out, M, HW, c, c, ACT_NONE, s, m.out_f32));
-    return;
+    return false;
   }
   bool tiled2;
   {
@@ -627,6 +633,7 @@ void mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
     PreOp gate{m.g, nullptr, nullptr};
     launch_conv_f(m.t1, P + m.w2, P + m.b2, x, m.out, g, gate, ACT_NONE, s);
   }
+  return false;
 }
 
 // returns the buffer holding d(loss)/d(block input); consumes (releases) `dout` when it is a pool buffer
@@ -747,6 +754,7 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
   if (sc.bf) need16(h, fused_dd);
   if (!fused_dd) launch_gemm_nn(sc.zs, P + sc.dd_w, P + sc.dd_b, sc.d0, nullptr, B, sc.z, (int)sc.K, ACT_NONE, s);
   const float* x = sc.d0;
+  bool chained = false;
   for (Block& blk : sc.dec) {
     if (blk.has_conv) {
       ConvGeom g = blk.cg; g.B = B;
@@ -759,7 +767,8 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
       }
       x = blk.cout;
     }
-    mn_forward(h, blk.mn, x, B, training, s, sc.bf);
+    MN* nextmn = (&blk != &sc.dec.back() && !(&blk + 1)->has_conv) ? &(&blk + 1)->mn : nullptr;
+    chained = mn_forward(h, blk.mn, x, B, training, s, sc.bf, nextmn, chained);
     x = blk.mn.out;
   }
   const int64_t M = (int64_t)B * sc.H * sc.W;
@@ -1092,6 +1101,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
         if (!cbf) launch_conv_f(sc.band, P + sc.cb_w, P + sc.cb_b, nullptr, sc.e0, g, none, ACT_ELU, ss);
       }
       const float* x = sc.e0;
+      bool chained = false;
       for (Block& blk : sc.enc) {
         if (blk.has_conv) {
           ConvGeom cg = blk.cg; cg.B = B;
@@ -1104,7 +1114,8 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
           }
           x = blk.cout;
         }
-        mn_forward(h, blk.mn, x, B, training, ss, sc.bf);
+        MN* nextmn = (&blk != &sc.enc.back() && !(&blk + 1)->has_conv) ? &(&blk + 1)->mn : nullptr;
+        chained = mn_forward(h, blk.mn, x, B, training, ss, sc.bf, nextmn, chained);
         x = blk.mn.out;
       }
       bool fused_heads;
