@@ -206,6 +206,8 @@ def main():
                 "algbw_GBps": nbytes / (ar_ms * 1e-3) / 1e9,
                 "busbw_GBps": nbytes / (ar_ms * 1e-3) / 1e9 * (2.0 * (n - 1) / n), "backend": rehearse or "nccl(RCCL)",
                 "world": world}
+        if world == 1:
+            coll["note"] = "world 1 (--force-collective): the all-reduce is an in-place no-op, the figure is its launch cost"
     m = eng.metrics()
     finite = bool(np.isfinite(m["r_exp"]) and np.isfinite(m["vae_kl_loss"]))
     # "also report forward+backward+ELBO without the optimiser" (secondary number, single GPU only)
@@ -282,6 +284,18 @@ def main():
                                    "ms_per_step_median_events": float(np.median(per2)),
                                    "hbm_frac": algorithmic_bytes_per_step(w, 128, act) / (dt2 / 30) / HBM_PEAK}
         e2.close()
+        if act == "f32":       # the same workload and batch with bfloat16 activation storage (not the headline: BASELINE's
+            # config 2 is float32) -- its own algorithmic bytes (2 bytes per activation element)
+            e3 = Engine(w["input_dims"], w["z_dims"], w["encoder"], w["decoder"], 0.0, 255.0, 0.01, B, act_dtype="bf16").bind(local)
+            e3.set_params(init_params(e3.param_table, 42))
+            s3 = lambda i: e3.train_step(x, lr, rf, kf, clip, seed=8000 + i)
+            for i in range(5):
+                s3(i)
+            dt3, per3 = timed_steps(e3, lambda i: s3(100 + i), 30, torch, dist, 1)
+            secondary["c32nb_b%d_bf16" % B] = {"images_per_sec": B * 30 / dt3, "ms_per_step": 1e3 * dt3 / 30,
+                                               "ms_per_step_median_events": float(np.median(per3)),
+                                               "hbm_frac": algorithmic_bytes_per_step(w, B, "bf16") / (dt3 / 30) / HBM_PEAK}
+            e3.close()
 
     ms = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
