@@ -236,6 +236,10 @@ constexpr int kDwMaxBlocks = 1024;     // partial-sum scratch: kDwMaxBlocks * 10
 bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, const float* w, const float* gate,
                          const float* dgap, float* dt0, float* dW, float* db, GradSlots sl, bool mask_in_lsb, int B, int H,
                          int W, int C, hipStream_t s, bool bf = false);
+// float32: conv2 of one MobileNetV3 block chained with conv0 of the next (kernels_mfma.hip: k_conv2_chain); false = not covered
+bool launch_conv2_chain(const float* X, const float* W, const float* bias, const float* gate, const float* residual,
+                        float* Y, const float* W2, const float* bias2, float* Y2, int64_t M, int64_t rows_per_image, int C,
+                        hipStream_t s);
 // bf16: conv2 of one MobileNetV3 block chained with conv0 of the next (k16_pw_chain); false = shape not covered
 bool launch16_pw_chain(const void* in, const float* w, const float* bias, const float* gate, const void* residual, void* out,
                        const float* w2, const float* bias2, void* out2, int64_t M, int64_t rows_per_image, int C,

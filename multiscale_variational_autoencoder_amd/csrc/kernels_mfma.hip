@@ -1445,6 +1445,148 @@ __global__ void __launch_bounds__(256, GR ? 2 : 4) k_conv0_tile(const float* __r
 #undef SWZ4
 }
 
+// conv2 of a MobileNetV3 block chained with conv0 of the NEXT block (both 64 -> 64; layer_blocks.py:625-641, then :594-602
+// of the following block): Y = (X * gate) . W + bias + residual is stored (it is the next block's residual and a saved
+// tensor) and goes back into the LDS tile, where the four waves read it as the A operand of Y2 = relu(Y . W2 + bias2):
+// the next block's conv0 does not read Y from HBM (one tensor pass less per block).
+__global__ void __launch_bounds__(256, 2) k_conv2_chain(const float* __restrict__ X, const float* __restrict__ W,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ gate,
+                                                                const float* __restrict__ residual,
+                                                                float* __restrict__ Y, const float* __restrict__ W2,
+                                                                const float* __restrict__ bias2, float* __restrict__ Y2,
+                                                                int64_t M, int64_t rows_per_image) {
+  constexpr int C = 64;
+  constexpr bool GR = true;
+  constexpr int KH = C / 2, NT = C / 32, C4 = C / 4, MASK = C4 - 1;
+  constexpr int WN = NT, WR = 4 / WN, TR = 32 * WR;
+  constexpr int LD = TR * C4 / 256;
+  static_assert(256 / C4 == 16 || !GR, "gated form: one staged float4 per 16-row group");
+  const ImgOf img_of(rows_per_image);
+  __shared__ __attribute__((aligned(16))) float sX[TR * C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = wave % WN, rw = wave / WN, n0 = nw * 32;
+  const int i = lane & 31, h = lane >> 5;
+  float breg[KH];                                          // Wm[k = h*KH + t][n = n0 + i] = W[k*C + n]
+#pragma unroll
+  for (int t = 0; t < KH; ++t) breg[t] = W[(int64_t)(h * KH + t) * C + n0 + i];
+  const float bz = bias ? bias[n0 + i] : 0.f;
+  float breg2[KH];
+#pragma unroll
+  for (int t = 0; t < KH; ++t) breg2[t] = W2[(int64_t)(h * KH + t) * C + n0 + i];
+  const float bz2 = bias2 ? bias2[n0 + i] : 0.f;
+#define SWZ1(r, c) ((r) * C + ((((c) >> 2) ^ ((r) & MASK)) << 2) + ((c) & 3))
+  const int64_t ntiles = M / TR;
+  const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
+  const f32x4* G4 = reinterpret_cast<const f32x4*>(gate);
+#define SWZ4(r, c4) ((r) * C4 + ((c4) ^ ((r) & MASK)))
+  struct Stage { f32x4 x[LD]; f32x4 g[GR ? LD : 1]; };
+  Stage S0, S1;
+  auto load_tile = [&](int64_t tile, Stage& S) {
+    const f32x4* px = X4 + tile * (TR * C4) + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < LD; ++j) S.x[j] = px[j * 256];
+    if constexpr (GR) {
+#pragma unroll
+      for (int j = 0; j < LD; ++j)
+        S.g[j] = G4[(int64_t)img_of(tile * TR + j * (256 / C4)) * C4 + threadIdx.x % C4];
+    }
+  };
+  float res[GR ? 16 : 1];
+  auto load_res = [&](int64_t tile) {
+    const float* pr = residual + (tile * TR + rw * 32 + 4 * h) * C + n0 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[GR ? r : 0] = pr[((r & 3) + 8 * (r >> 2)) * C];
+  };
+  int64_t tile = blockIdx.x;
+  const int64_t g1 = gridDim.x, g2 = 2 * g1;
+  if (tile < ntiles) {
+    load_tile(tile, S0);
+    load_tile(tile + g1 < ntiles ? tile + g1 : tile, S1);
+    if constexpr (GR) load_res(tile);
+  }
+  auto body = [&](int64_t tile, Stage& S, int64_t next_res) {
+    const int64_t row0 = tile * TR + rw * 32;
+    __syncthreads();                                       // previous tile's fragments are in registers everywhere
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+      const int idx = j * 256 + threadIdx.x;
+      f32x4 v = S.x[j];
+      if constexpr (GR) v = v * S.g[j];
+      reinterpret_cast<f32x4*>(sX)[SWZ4(idx / C4, idx % C4)] = v;
+    }
+    __syncthreads();
+    load_tile(tile + g2 < ntiles ? tile + g2 : tile, S);   // two tiles ahead, ahead of this tile's stores
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int QH = KH / 8 > 0 ? KH / 8 : 1, NB = (KH / 4) / QH;
+#pragma unroll
+    for (int bq = 0; bq < NB; ++bq) {
+      f32x4 afr[QH];
+#pragma unroll
+      for (int q = 0; q < QH; ++q)
+        afr[q] = reinterpret_cast<const f32x4*>(sX)[SWZ4(rw * 32 + i, h * (C4 / 2) + bq * QH + q)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < QH; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg[(bq * QH + q) * 4 + e], acc, 0, 0, 0);
+    }
+    float* py = Y + (row0 + 4 * h) * C + n0 + i;           // accumulator layout: two 128-byte row segments per store
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += bz + res[r];
+    load_res(next_res);                                    // next tile's residual: requested BEFORE this tile's stores
+#pragma unroll
+    for (int r = 0; r < 16; ++r) py[((r & 3) + 8 * (r >> 2)) * C] = acc[r];
+    // ---- the Y tile back into the LDS tile (all waves have their X fragments), then Y2 = relu(Y . W2 + bias2)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sX[SWZ1(rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + i)] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int bq = 0; bq < NB; ++bq) {
+      f32x4 afr[QH];
+#pragma unroll
+      for (int q = 0; q < QH; ++q)
+        afr[q] = reinterpret_cast<const f32x4*>(sX)[SWZ4(rw * 32 + i, h * (C4 / 2) + bq * QH + q)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < QH; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], breg2[(bq * QH + q) * 4 + e], acc, 0, 0, 0);
+    }
+    float* py2 = Y2 + (row0 + 4 * h) * C + n0 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) py2[((r & 3) + 8 * (r >> 2)) * C] = fmaxf(acc[r] + bz2, 0.f);
+  };
+  // This block's tiles are tile, tile + g1, ...: `mine` of them.  They are processed in pairs by a loop with a FIXED trip
+  // count and no exit in the middle (an early `break` between the two halves let LLVM sink the first half's prefetch
+  // below it -- behind the stores); the first pair is peeled (counted vmcnt waits), an odd last tile follows the loop.
+  const int64_t mine = tile < ntiles ? (ntiles - tile + g1 - 1) / g1 : 0;
+  const int64_t last = tile + (mine > 0 ? mine - 1 : 0) * g1;
+  auto nxt = [&](int64_t t) { return t + g1 <= last ? t + g1 : t; };
+  if (mine >= 2) {
+    body(tile, S0, tile + g1);
+    body(tile + g1, S1, nxt(tile + g1));
+    tile += g2;
+    for (int64_t p = 1; p < mine / 2; ++p) {
+      body(tile, S0, tile + g1);
+      body(tile + g1, S1, nxt(tile + g1));
+      tile += g2;
+    }
+  }
+  if (mine & 1) body(tile, S0, tile);
+#undef SWZ4
+#undef SWZ1
+}
+
+
 // conv0: Y = relu(X . W + b);  conv2 (gate != null): Y = (X * gate[image]) . W + b + residual.   C -> C.
 // false = shape not covered (the caller uses k_gemm_rows)
 bool launch_conv0_tile(const float* X, const float* W, const float* bias, const float* gate, const float* residual,
@@ -1461,6 +1603,20 @@ bool launch_conv0_tile(const float* X, const float* W, const float* bias, const 
   if (gr) hipLaunchKernelGGL((k_conv0_tile<64, true>), dim3(grid), dim3(256), 0, s, X, W, bias, gate, residual, Y, M, rows_per_image);
   else if (C == 64) hipLaunchKernelGGL((k_conv0_tile<64, false>), dim3(grid), dim3(256), 0, s, X, W, bias, gate, residual, Y, M, rows_per_image);
   else hipLaunchKernelGGL((k_conv0_tile<32, false>), dim3(grid), dim3(256), 0, s, X, W, bias, gate, residual, Y, M, rows_per_image);
+  return true;
+}
+
+// conv2 of a block + conv0 of the next in one launch (k_conv2_chain).  false = shape not covered / switched off.
+bool launch_conv2_chain(const float* X, const float* W, const float* bias, const float* gate, const float* residual,
+                        float* Y, const float* W2, const float* bias2, float* Y2, int64_t M, int64_t rows_per_image, int C,
+                        hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("MVAE_FUSE_PW_CHAIN"); return e ? atoi(e) != 0 : true; }();
+  if (!on || C != 64 || !gate || !residual || rows_per_image % 16 != 0) return false;
+  if (M % 64 != 0 || M < 256 * 64) return false;
+  const int64_t ntiles = M / 64;
+  const int cap = 2 * big_grid_cus();
+  const int grid = (int)(ntiles < cap ? ntiles : cap);
+  hipLaunchKernelGGL(k_conv2_chain, dim3(grid), dim3(256), 0, s, X, W, bias, gate, residual, Y, W2, bias2, Y2, M, rows_per_image);
   return true;
 }
 

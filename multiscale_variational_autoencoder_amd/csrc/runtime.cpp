@@ -590,7 +590,7 @@ bool mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
   PreOp none{nullptr, nullptr, nullptr};
   if (bf) {
     if (!conv0_done) need16(h, launch16_pw(false, x, P + m.w0, P + m.b0, nullptr, nullptr, m.t0, M, HW, c, c, ACT_RELU, s));
-  } else {
+  } else if (!conv0_done) {
     bool tiled0;
     {
       ProfScope ps("k_conv0_tile", 8.0 * B * m.H * m.W * c, 2.0 * B * m.H * m.W * c * c, s);
@@ -623,6 +623,11 @@ bool mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
       return true;
     need16(h, launch16_pw(false, m.t1, P + m.w2, P + m.b2, m.g, x, m.out, M, HW, c, c, ACT_NONE, s, m.out_f32));
     return false;
+  }
+  if (chain && chain->c == c && chain->H == m.H && chain->W == m.W) {
+    ProfScope ps("k_conv2_chain", 16.0 * B * m.H * m.W * c, 4.0 * B * m.H * m.W * c * c, s);
+    if (launch_conv2_chain(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, P + chain->w0, P + chain->b0, chain->t0, M, HW, c, s))
+      return true;
   }
   bool tiled2;
   {
