@@ -1,0 +1,79 @@
+"""GPU: the fused launches against the launches they replace.  The switches are read once per process
+(MVAE_FUSE_PW_CHAIN: conv2 + next block's conv0 in one launch, float32 and bf16; MVAE_FUSE_DW_CONV0: depthwise
+backward + conv0's backward pair, bf16), so each variant runs in a subprocess.  Fused and separate launches round at
+the same points; what differs between two runs is what differs between ANY two runs of this engine: the order of the
+forward's float atomics (GAP, BatchNorm sums).  In float32 that is 1e-6 on the forward tensors, but a ReLU unit within
+rounding of zero can land on the other side and move one weight gradient by ~1e-3 at this batch size (DESIGN.md section 2,
+kinks); in bf16 it re-rolls roundings downstream (a few pixels of the reconstruction move by percents of the range).
+The bars below are those run-to-run levels -- a wrong tile mapping or a dropped term shows as O(1).  This also keeps the
+separate-launch kernels (the fallback for shapes the fused ones do not cover) under test."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.common import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import sys, os, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests.common import COMPILE, engine_args, make_inputs
+from multiscale_variational_autoencoder_amd.engine import Engine
+name, B, dt, out = sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+io = make_inputs(name, B)
+eng = Engine(**engine_args(name, B), act_dtype=dt).bind()
+eng.set_params(io["params"]); eng.set_state(io["state"])
+d = {k: eng.to_device(io[k]) for k in ("x", "eps", "noise", "keep")}
+res = eng.forward(d["x"], True, d["eps"], d["noise"], d["keep"], outputs=("recon", "losses"))
+eng.backward(COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"])
+g = eng.get_grads()
+np.savez(out, recon=res["recon"].cpu().numpy(), losses=res["losses"].cpu().numpy(), **{"g/" + k: v for k, v in g.items()})
+'''
+
+
+def _run(tmp_path, tag, env, name, B, dt):
+    out = str(tmp_path / ("%s.npz" % tag))
+    e = dict(os.environ)
+    e.update(env)
+    subprocess.run([sys.executable, "-c", WORKER, ROOT, name, str(B), dt, out], check=True, env=e, timeout=600)
+    return np.load(out)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dt,tol_max,tol_rms,tol_grad", [("f32", 1e-4, 1e-5, 2e-3), ("bf16", 0.1, 5e-3, 0.35)])
+def test_fused_launches_equal_separate_launches(tmp_path, dt, tol_max, tol_rms, tol_grad):
+    """c64nb, batch 4: 64 / 32 / 16 wide scales (halo and no-halo strips of the fused depthwise kernel, the chained and
+    the separate conv2 / conv0).  bf16 gradients: a last-bit difference of a float-atomic sum in the forward pass (GAP,
+    BatchNorm statistics) can re-roll a bf16 rounding downstream, hence the wider bar there."""
+    name, B = "c64nb", 4
+    on = _run(tmp_path, "on", {"MVAE_FUSE_PW_CHAIN": "1", "MVAE_FUSE_DW_CONV0": "1"}, name, B, dt)
+    off = _run(tmp_path, "off", {"MVAE_FUSE_PW_CHAIN": "0", "MVAE_FUSE_DW_CONV0": "0"}, name, B, dt)
+    diff = on["recon"].astype(np.float64) - off["recon"]
+    assert np.abs(diff).max() <= tol_max * 255.0 and np.sqrt((diff ** 2).mean()) <= tol_rms * 255.0
+    assert np.abs(on["losses"] - off["losses"]).max() <= (1e-4 if dt == "f32" else 2e-2) * np.abs(off["losses"]).max()
+    keys = [k for k in off.files if k.startswith("g/")]
+    assert len(keys) > 100
+    rms = np.sqrt(sum(float((off[k].astype(np.float64) ** 2).sum()) for k in keys) / sum(off[k].size for k in keys))
+    # weights against tol_grad; bias vectors (plain column sums: cancellation noise, and the ones that feed a BatchNorm
+    # have a true gradient of exactly zero) against 10x that
+    worst, worst_b, errs = ("", 0.0), ("", 0.0), []
+    for k in keys:
+        a, b = on[k].astype(np.float64), off[k].astype(np.float64)
+        err = float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 0.1 * rms * np.sqrt(b.size)))
+        errs.append(err)
+        if k.endswith(".b") or b.ndim == 1:
+            worst_b = max(worst_b, (k, err), key=lambda kv: kv[1])
+        else:
+            worst = max(worst, (k, err), key=lambda kv: kv[1])
+    with open(os.path.join(ROOT, "gpurun_out", "fusion_ab_%s.json" % dt), "w") as f:
+        json.dump({"worst_weight": worst, "worst_vector": worst_b, "median": float(np.median(errs))}, f)
+    assert worst[1] <= tol_grad, worst
+    # bf16 at batch 4: the decoder's bias gradients are sums of bf16-rounded terms that cancel almost completely (two
+    # bf16 runs of the SAME build differ by O(1) there, tests/test_bf16_gpu.py); the typical tensor is the measure
+    assert worst_b[1] <= (10 * tol_grad if dt == "f32" else 5.0), worst_b
+    assert np.median(errs) <= (1e-5 if dt == "f32" else 1e-2), float(np.median(errs))
