@@ -240,8 +240,10 @@ bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, con
 bool launch_conv2_chain(const float* X, const float* W, const float* bias, const float* gate, const float* residual,
                         float* Y, const float* W2, const float* bias2, float* Y2, int64_t M, int64_t rows_per_image, int C,
                         hipStream_t s);
-// bf16: conv2 of one MobileNetV3 block chained with conv0 of the next (k16_pw_chain); false = shape not covered
+// bf16: conv2 of one MobileNetV3 block chained with conv0 of the next (k16_pw_chain), optionally through the 1x1
+// convolution 64 -> 32 between them (wm / biasm / outm; mid_transposed = Conv2DTranspose form); false = shape not covered
 bool launch16_pw_chain(const void* in, const float* w, const float* bias, const float* gate, const void* residual, void* out,
+                       const float* wm, const float* biasm, void* outm, bool mid_transposed,
                        const float* w2, const float* bias2, void* out2, int64_t M, int64_t rows_per_image, int C,
                        hipStream_t s);
 // bf16: that depthwise backward fused with conv0's backward pair (kernels_bf16.hip: k16_dw_bwd_conv0) -- da = dt0 . W0^T +

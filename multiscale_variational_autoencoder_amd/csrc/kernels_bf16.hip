@@ -281,13 +281,21 @@ __global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, cons
 // second product, so Y is not read back (one tensor pass less per block).  The second product sees the bf16-rounded Y,
 // as the separate launch would.  W2 fragments and bias2 sit in LDS (registers: 208 + 16).
 // =================================================================================================
+// MID: between the two blocks sits a 1x1 convolution 64 -> 32 (basic_block's Conv2D / Conv2DTranspose of the last
+// level, layer_blocks.py:946-951; WTM = the transposed form) and the next block is 32 wide: three products in a row,
+//   Y = conv2(X) (stored), Ym = Y . Wm + bm (stored: the next block's residual / conv output), Y2 = relu(Ym . W2 + b2),
+// each from the chunks the previous one has just stored (Ym's two chunks per lane are the K = 32 fragments of the third).
+template <bool MID, bool WTM>
 __global__ void __launch_bounds__(256) k16_pw_chain(const bf16_t* __restrict__ X, const float* __restrict__ W,
                                                     const float* __restrict__ bias, const float* __restrict__ gate,
                                                     const bf16_t* __restrict__ res, bf16_t* __restrict__ Y,
+                                                    const float* __restrict__ Wm, const float* __restrict__ biasm,
+                                                    bf16_t* __restrict__ Ym,
                                                     const float* __restrict__ W2, const float* __restrict__ bias2,
                                                     bf16_t* __restrict__ Y2, int64_t ntiles, int64_t rows_per_image) {
   constexpr int K = 64, N = 64, TB = 32 * K * 2, RB = 32 * N * 2;
-  __shared__ __attribute__((aligned(16))) char lds[4 * (TB + RB) + 8 * 64 * 16 + 64 * 4];
+  constexpr int N2 = MID ? 32 : 64;                                     // width of the next block
+  __shared__ __attribute__((aligned(16))) char lds[4 * (TB + RB) + 8 * 64 * 16 + 64 * 4 + (MID ? 4 * 64 * 16 + 32 * 4 : 0)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   char* tile = lds + wave * (TB + RB);
@@ -296,14 +304,33 @@ __global__ void __launch_bounds__(256) k16_pw_chain(const bf16_t* __restrict__ X
   float* b2s = reinterpret_cast<float*>(lds + 4 * (TB + RB) + 8 * 64 * 16);
   bf16x8 wf[2][4];
   load_wfrags<K, N, false>(W, r, h, wf);
+  u32x4* wflm = reinterpret_cast<u32x4*>(lds + 4 * (TB + RB) + 8 * 64 * 16 + 64 * 4);
+  float* bms = reinterpret_cast<float*>(lds + 4 * (TB + RB) + 8 * 64 * 16 + 64 * 4 + 4 * 64 * 16);
   if (wave == 0) {
-    bf16x8 w2[2][4];
-    load_wfrags<64, 64, false>(W2, r, h, w2);
+    if constexpr (MID) {
+      bf16x8 w2[1][2];
+      load_wfrags<32, 32, false>(W2, r, h, w2);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+      for (int kk = 0; kk < 2; ++kk) wfl2[kk * 64 + lane] = __builtin_bit_cast(u32x4, w2[0][kk]);
+      if (lane < 32) b2s[lane] = bias2 ? bias2[lane] : 0.f;
+    } else {
+      bf16x8 w2[2][4];
+      load_wfrags<64, 64, false>(W2, r, h, w2);
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) wfl2[(nt * 4 + kk) * 64 + lane] = __builtin_bit_cast(u32x4, w2[nt][kk]);
-    b2s[lane] = bias2 ? bias2[lane] : 0.f;
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wfl2[(nt * 4 + kk) * 64 + lane] = __builtin_bit_cast(u32x4, w2[nt][kk]);
+      b2s[lane] = bias2 ? bias2[lane] : 0.f;
+    }
+  }
+  if constexpr (MID) {
+    if (wave == 1) {
+      bf16x8 wm[1][4];
+      load_wfrags<64, 32, WTM>(Wm, r, h, wm);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wflm[kk * 64 + lane] = __builtin_bit_cast(u32x4, wm[0][kk]);
+      if (lane < 32) bms[lane] = biasm ? biasm[lane] : 0.f;
+    }
   }
   f32x4 bz[2][4];
 #pragma unroll
@@ -373,6 +400,54 @@ __global__ void __launch_bounds__(256) k16_pw_chain(const bf16_t* __restrict__ X
         *reinterpret_cast<u32x4*>(Y + rowoff + nt * 32 + 16 * p + 8 * h) = o[2 * nt + p];
       }
     }
+    if constexpr (MID) {
+      // ---- Ym = Y . Wm + bm (32 channels), then Y2 = relu(Ym . W2 + b2) from Ym's two chunks
+      acc[0] = zero16();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wflm[kk * 64 + lane]), as_frag(o[kk]), acc[0], 0, 0, 0);
+      const int64_t rowm = (row0 + r) * 32;
+      u32x4 om[2];
+      {
+        uint2 pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = {acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]};
+          v += *reinterpret_cast<const f32x4*>(bms + 8 * q + 4 * h);
+          pk[q] = pack4(v);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          uint2 a = pk[2 * p], b = pk[2 * p + 1];
+          auto s0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+          om[p] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          *reinterpret_cast<u32x4*>(Ym + rowm + 16 * p + 8 * h) = om[p];
+        }
+      }
+      acc[0] = zero16();
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wfl2[kk * 64 + lane]), as_frag(om[kk]), acc[0], 0, 0, 0);
+      {
+        uint2 pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = {acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]};
+          v += *reinterpret_cast<const f32x4*>(b2s + 8 * q + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          pk[q] = pack4(v);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          uint2 a = pk[2 * p], b = pk[2 * p + 1];
+          auto s0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+          *reinterpret_cast<u32x4*>(Y2 + rowm + 16 * p + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
+      }
+    } else {
     // ---- Y2 = relu(Y . W2 + bias2): the chunks above are the B fragments
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc[nt] = zero16();
@@ -401,6 +476,7 @@ __global__ void __launch_bounds__(256) k16_pw_chain(const bf16_t* __restrict__ X
         *reinterpret_cast<u32x4*>(Y2 + rowoff + nt * 32 + 16 * p + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
       }
     }
+    }   // !MID
     cur = nxt; rcur = rnxt; gc0 = gn0; gc1 = gn1;
   }
 }
@@ -915,8 +991,10 @@ bool launch16_pw(bool transposed, const void* in, const float* w, const float* b
   return false;
 }
 
-// conv2 of a block chained with conv0 of the next one (k16_pw_chain; both 64 -> 64).  false = shape not covered.
+// conv2 of a block chained with conv0 of the next one (k16_pw_chain; both 64 -> 64); with wm: a 1x1 convolution 64 -> 32
+// (mid_transposed: the Conv2DTranspose form) sits between them and the next block is 32 wide.  false = not covered.
 bool launch16_pw_chain(const void* in, const float* w, const float* bias, const float* gate, const void* residual, void* out,
+                       const float* wm, const float* biasm, void* outm, bool mid_transposed,
                        const float* w2, const float* bias2, void* out2, int64_t M, int64_t rows_per_image, int C,
                        hipStream_t s) {
   static const bool on = [] { const char* e = getenv("MVAE_FUSE_PW_CHAIN"); return e ? atoi(e) != 0 : true; }();
@@ -924,9 +1002,15 @@ bool launch16_pw_chain(const void* in, const float* w, const float* bias, const 
   const int64_t ntiles = M / 32;
   const int64_t nblk = (ntiles + 3) / 4;
   const int grid = (int)(nblk < 4 * cus16() ? nblk : 4 * cus16());
-  ProfScope ps("k16_pw_chain", 2.0 * M * C * 4, 4.0 * M * C * C, s);
-  hipLaunchKernelGGL(k16_pw_chain, dim3(grid), dim3(256), 0, s, (const bf16_t*)in, w, bias, gate, (const bf16_t*)residual,
-                     (bf16_t*)out, w2, bias2, (bf16_t*)out2, ntiles, rows_per_image);
+  ProfScope ps(wm ? "k16_pw_chain3" : "k16_pw_chain", 2.0 * M * (wm ? 3 * C + 64 : 4 * C), (wm ? 2.0 * C * C + 2.0 * C * 32 + 2.0 * 32 * 32 : 4.0 * C * C) * M, s);
+#define MVAE_CH(MID_, WT_)                                                                                             \
+  hipLaunchKernelGGL((k16_pw_chain<MID_, WT_>), dim3(grid), dim3(256), 0, s, (const bf16_t*)in, w, bias, gate,         \
+                     (const bf16_t*)residual, (bf16_t*)out, wm, biasm, (bf16_t*)outm, w2, bias2, (bf16_t*)out2, ntiles, \
+                     rows_per_image)
+  if (!wm) MVAE_CH(false, false);
+  else if (mid_transposed) MVAE_CH(true, true);
+  else MVAE_CH(true, false);
+#undef MVAE_CH
   return true;
 }
 

@@ -579,9 +579,12 @@ ConvGeom geom1x1(int B, int H, int W, int ci, int co) {
 inline void need16(mvae_handle* h, bool ok) { if (!ok) h->kernel_gap = true; }
 
 // chain: the NEXT block of the same shape (no convolution in between), whose conv0 this block's conv2 launch also
-// computes (bf16, 64 channels); conv0_done: this block's conv0 was computed that way.  Returns whether it chained.
-bool mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipStream_t s, bool bf, MN* chain = nullptr,
-                bool conv0_done = false) {
+// computes (64 channels); chain3 (bf16): the next Block when a 1x1 convolution 64 -> 32 sits between the two and the next
+// block is 32 wide -- that convolution and the next conv0 then ride along too.  conv0_done: this block's conv0 was
+// computed by the previous block's launch.  Returns 0 = nothing chained, 1 = the next conv0 is done, 2 = the next
+// block's convolution and conv0 are done.
+int mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipStream_t s, bool bf, MN* chain = nullptr,
+               bool conv0_done = false, Block* chain3 = nullptr, bool chain3_transposed = false) {
   const float* P = h->dp;
   float* stats = h->dr + h->P;
   const int c = m.c;
@@ -619,15 +622,20 @@ bool mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
   }
   if (bf) {
     if (chain && !m.out_f32 && chain->c == c && chain->H == m.H && chain->W == m.W &&
-        launch16_pw_chain(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, P + chain->w0, P + chain->b0, chain->t0, M, HW, c, s))
-      return true;
+        launch16_pw_chain(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, nullptr, nullptr, nullptr, false, P + chain->w0,
+                          P + chain->b0, chain->t0, M, HW, c, s))
+      return 1;
+    if (chain3 && !m.out_f32 && c == 64 && chain3->mn.c == 32 && chain3->mn.H == m.H && chain3->mn.W == m.W &&
+        launch16_pw_chain(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, P + chain3->cw, P + chain3->cb, chain3->cout,
+                          chain3_transposed, P + chain3->mn.w0, P + chain3->mn.b0, chain3->mn.t0, M, HW, c, s))
+      return 2;
     need16(h, launch16_pw(false, m.t1, P + m.w2, P + m.b2, m.g, x, m.out, M, HW, c, c, ACT_NONE, s, m.out_f32));
-    return false;
+    return 0;
   }
   if (chain && chain->c == c && chain->H == m.H && chain->W == m.W) {
     ProfScope ps("k_conv2_chain", 16.0 * B * m.H * m.W * c, 4.0 * B * m.H * m.W * c * c, s);
     if (launch_conv2_chain(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, P + chain->w0, P + chain->b0, chain->t0, M, HW, c, s))
-      return true;
+      return 1;
   }
   bool tiled2;
   {
@@ -638,7 +646,7 @@ bool mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hip
     PreOp gate{m.g, nullptr, nullptr};
     launch_conv_f(m.t1, P + m.w2, P + m.b2, x, m.out, g, gate, ACT_NONE, s);
   }
-  return false;
+  return 0;
 }
 
 // returns the buffer holding d(loss)/d(block input); consumes (releases) `dout` when it is a pool buffer
@@ -759,9 +767,11 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
   if (sc.bf) need16(h, fused_dd);
   if (!fused_dd) launch_gemm_nn(sc.zs, P + sc.dd_w, P + sc.dd_b, sc.d0, nullptr, B, sc.z, (int)sc.K, ACT_NONE, s);
   const float* x = sc.d0;
-  bool chained = false;
+  int chained = 0;
   for (Block& blk : sc.dec) {
-    if (blk.has_conv) {
+    if (blk.has_conv && chained == 2) {
+      x = blk.cout;                                   // computed by the previous block's conv2 launch
+    } else if (blk.has_conv) {
       ConvGeom g = blk.cg; g.B = B;
       if (sc.bf) {
         if (g.KH * g.KW == 1) need16(h, launch16_pw(true, x, P + blk.cw, P + blk.cb, nullptr, nullptr, blk.cout,
@@ -772,8 +782,11 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
       }
       x = blk.cout;
     }
-    MN* nextmn = (&blk != &sc.dec.back() && !(&blk + 1)->has_conv) ? &(&blk + 1)->mn : nullptr;
-    chained = mn_forward(h, blk.mn, x, B, training, s, sc.bf, nextmn, chained);
+    Block* nb = &blk != &sc.dec.back() ? &blk + 1 : nullptr;
+    MN* nextmn = (nb && !nb->has_conv) ? &nb->mn : nullptr;
+    Block* next3 = (sc.bf && nb && nb->has_conv && nb->cg.KH * nb->cg.KW == 1 && nb->cg.SH == 1 && nb->cg.SW == 1 &&
+                    nb->cg.CO == 64 && nb->cg.CI == 32) ? nb : nullptr;          // convT: CO = its input, CI = its output
+    chained = mn_forward(h, blk.mn, x, B, training, s, sc.bf, nextmn, chained != 0, next3, true);
     x = blk.mn.out;
   }
   const int64_t M = (int64_t)B * sc.H * sc.W;
@@ -1106,9 +1119,11 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
         if (!cbf) launch_conv_f(sc.band, P + sc.cb_w, P + sc.cb_b, nullptr, sc.e0, g, none, ACT_ELU, ss);
       }
       const float* x = sc.e0;
-      bool chained = false;
+      int chained = 0;
       for (Block& blk : sc.enc) {
-        if (blk.has_conv) {
+        if (blk.has_conv && chained == 2) {
+          x = blk.cout;                               // computed by the previous block's conv2 launch
+        } else if (blk.has_conv) {
           ConvGeom cg = blk.cg; cg.B = B;
           if (sc.bf) {
             if (cg.KH * cg.KW == 1) need16(h, launch16_pw(false, x, P + blk.cw, P + blk.cb, nullptr, nullptr, blk.cout,
@@ -1119,8 +1134,11 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
           }
           x = blk.cout;
         }
-        MN* nextmn = (&blk != &sc.enc.back() && !(&blk + 1)->has_conv) ? &(&blk + 1)->mn : nullptr;
-        chained = mn_forward(h, blk.mn, x, B, training, ss, sc.bf, nextmn, chained);
+        Block* nb = &blk != &sc.enc.back() ? &blk + 1 : nullptr;
+        MN* nextmn = (nb && !nb->has_conv) ? &nb->mn : nullptr;
+        Block* next3 = (sc.bf && nb && nb->has_conv && nb->cg.KH * nb->cg.KW == 1 && nb->cg.SH == 1 && nb->cg.SW == 1 &&
+                        nb->cg.CI == 64 && nb->cg.CO == 32) ? nb : nullptr;
+        chained = mn_forward(h, blk.mn, x, B, training, ss, sc.bf, nextmn, chained != 0, next3, false);
         x = blk.mn.out;
       }
       bool fused_heads;
