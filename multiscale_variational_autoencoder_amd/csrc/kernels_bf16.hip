@@ -652,11 +652,31 @@ __global__ void __launch_bounds__(256) k16_dual(const bf16_t* __restrict__ X, co
 // with coalesced 16-byte loads (SAME padding = an out-of-range buffer offset, which returns zeros), one tap ahead of the
 // MFMAs, and stages them in a wave-private LDS tile from which the B fragments (lane = pixel) are read.
 // =================================================================================================
-template <int KC, int NC, bool TFORM, int MAXTAPS, int NTHR>
+// CHAIN (T-form, NC = 64): the MobileNetV3 block that follows the transposed convolution starts with conv0 (64 -> 64,
+// bias, ReLU): out2 = relu(out . W2 + bias2) is computed from the chunks just stored (see k16_pw_chain), so that block's
+// conv0 does not read `out` back.
+template <int KC, int NC, bool TFORM, int MAXTAPS, int NTHR, bool CHAIN = false>
 __global__ void __launch_bounds__(NTHR) k16_taps(const bf16_t* __restrict__ in, const float* __restrict__ W,
                                                 const float* __restrict__ bias, bf16_t* __restrict__ out, ConvGeom g,
-                                                unsigned in_bytes, int tiles_per_wave) {
+                                                unsigned in_bytes, int tiles_per_wave, const float* __restrict__ W2,
+                                                const float* __restrict__ bias2, bf16_t* __restrict__ out2) {
   constexpr int NT = NC / 32, KK = KC / 16;
+  static_assert(!CHAIN || (TFORM && NC == 64), "chained conv0: T-form, 64 output channels");
+  __shared__ __attribute__((aligned(16))) char sW2[CHAIN ? 8 * 64 * 16 + 64 * 4 : 16];
+  u32x4* wfl2 = reinterpret_cast<u32x4*>(sW2);
+  float* b2s = reinterpret_cast<float*>(sW2 + 8 * 64 * 16);
+  if constexpr (CHAIN) {
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x;
+      bf16x8 w2[2][4];
+      load_wfrags<64, 64, false>(W2, l & 31, l >> 5, w2);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wfl2[(nt * 4 + kk) * 64 + l] = __builtin_bit_cast(u32x4, w2[nt][kk]);
+      b2s[l] = bias2 ? bias2[l] : 0.f;
+    }
+  }
   constexpr int CPP = KC / 8, LX = KC / 16;          // 16-byte chunks per pixel; gather slots per lane (32 px * CPP / 64)
   __shared__ __attribute__((aligned(16))) char sW[MAXTAPS * NC * KC * 2];
   __shared__ __attribute__((aligned(16))) char sA[(NTHR / 64) * 32 * KC * 2];
@@ -777,6 +797,7 @@ __global__ void __launch_bounds__(NTHR) k16_taps(const bf16_t* __restrict__ in, 
     int cx, cy, b;
     split(p < Mc ? p : 0u, cx, cy, b);
     const int64_t opix = TFORM ? ((int64_t)(b * g.IH + (cy * g.SH + py)) * g.IW + (cx * g.SW + px)) : (int64_t)(p < Mc ? p : 0u);
+    u32x4 och[CHAIN ? 4 : 1];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       uint2 pk[4];
@@ -792,7 +813,36 @@ __global__ void __launch_bounds__(NTHR) k16_taps(const bf16_t* __restrict__ in, 
         auto s0 = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
         auto s1 = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+        if constexpr (CHAIN) och[2 * nt + pp] = o;
         if (p < Mc) *reinterpret_cast<u32x4*>(out + opix * NC + nt * 32 + 16 * pp + 8 * h) = o;
+      }
+    }
+    if constexpr (CHAIN) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[nt] = zero16();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wfl2[(nt * 4 + kk) * 64 + lane]), as_frag(och[kk]), acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        uint2 pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = {acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
+          v += *reinterpret_cast<const f32x4*>(b2s + nt * 32 + 8 * q + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          pk[q] = pack4(v);
+        }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          uint2 a = pk[2 * pp], bb = pk[2 * pp + 1];
+          auto s0 = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
+          if (p < Mc) *reinterpret_cast<u32x4*>(out2 + opix * 64 + nt * 32 + 16 * pp + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
       }
     }
   }
@@ -1306,7 +1356,8 @@ bool launch16_dw_bwd_conv0(const void* dt2, const void* t0, const float* w, cons
 
 // k x k convolution (F-form: in = big) / transposed convolution (T-form: in = small).  false = shape not covered.
 bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g,
-                   hipStream_t s) {
+                   hipStream_t s, const float* w2, const float* bias2, void* out2, bool* chained) {
+  if (chained) *chained = false;
   const int KC = transposed ? g.CO : g.CI, NC = transposed ? g.CI : g.CO;
   if ((int64_t)g.B * g.IH * g.IW * g.CI * 2 >= (1LL << 31) || (int64_t)g.B * g.OH * g.OW * g.CO * 2 >= (1LL << 31)) return false;
   if (g.KH > 8 || g.KW > 8 || g.KH * g.KW > 25) return false;
@@ -1331,8 +1382,15 @@ bool launch16_taps(bool transposed, const void* in, const float* w, const float*
                2.0 * g.B * g.OH * g.OW * g.CO * g.KH * g.KW * g.CI, s);
 #define MVAE_T16(A, B_, TF, MT, NW)                                                                                   \
   hipLaunchKernelGGL((k16_taps<A, B_, TF, MT, 64 * NW>), dim3(gx, classes), dim3(64 * NW), 0, s,                      \
-                     (const bf16_t*)in, w, bias, (bf16_t*)out, g, in_bytes, tpw)
+                     (const bf16_t*)in, w, bias, (bf16_t*)out, g, in_bytes, tpw, nullptr, nullptr, nullptr)
   if (transposed && (((g.KH + g.SH - 1) / g.SH) * ((g.KW + g.SW - 1) / g.SW) > 9)) return false;   // taps per phase
+  static const bool chain_on = [] { const char* e = getenv("MVAE_FUSE_PW_CHAIN"); return e ? atoi(e) != 0 : true; }();
+  if (KC == 32 && NC == 64 && transposed && w2 && out2 && chain_on) {
+    hipLaunchKernelGGL((k16_taps<32, 64, true, 9, 512, true>), dim3(gx, classes), dim3(512), 0, s, (const bf16_t*)in, w, bias,
+                       (bf16_t*)out, g, in_bytes, tpw, w2, bias2, (bf16_t*)out2);
+    if (chained) *chained = true;
+    return true;
+  }
   if (KC == 32 && NC == 64) { if (transposed) MVAE_T16(32, 64, true, 9, 8); else MVAE_T16(32, 64, false, 25, 16); }
   else { if (transposed) MVAE_T16(64, 32, true, 9, 8); else MVAE_T16(64, 32, false, 25, 12); }
 #undef MVAE_T16

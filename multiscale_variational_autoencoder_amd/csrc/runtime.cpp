@@ -27,7 +27,8 @@ bool launch16_dual(const void* X, const float* W, const void* aux, const float* 
                    float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C, GradSlots sl,
                    hipStream_t s, bool embed_mask = false);
 bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g,
-                   hipStream_t s);
+                   hipStream_t s, const float* w2 = nullptr, const float* bias2 = nullptr, void* out2 = nullptr,
+                   bool* chained = nullptr);   // w2 / out2: the following block's conv0 rides along (T-form 32 -> 64)
 bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s);
 }
 
@@ -776,7 +777,13 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
       if (sc.bf) {
         if (g.KH * g.KW == 1) need16(h, launch16_pw(true, x, P + blk.cw, P + blk.cb, nullptr, nullptr, blk.cout,
                                                     (int64_t)B * g.IH * g.IW, (int64_t)g.IH * g.IW, g.CO, g.CI, ACT_NONE, s));
-        else need16(h, launch16_taps(true, x, P + blk.cw, P + blk.cb, blk.cout, g, s));
+        else {
+          bool c0 = false;                            // the block's conv0 from the chunks the convT has just stored
+          const bool want = blk.mn.c == 64 && g.CI == 64;
+          need16(h, launch16_taps(true, x, P + blk.cw, P + blk.cb, blk.cout, g, s, want ? P + blk.mn.w0 : nullptr,
+                                  want ? P + blk.mn.b0 : nullptr, want ? blk.mn.t0 : nullptr, &c0));
+          if (c0) chained = 1;
+        }
       } else {
         launch_conv_t(x, P + blk.cw, P + blk.cb, nullptr, blk.cout, g, s);
       }

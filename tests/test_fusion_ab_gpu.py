@@ -45,7 +45,7 @@ def _run(tmp_path, tag, env, name, B, dt):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("dt,tol_max,tol_rms,tol_grad", [("f32", 1e-4, 1e-5, 2e-3), ("bf16", 0.1, 5e-3, 0.35)])
+@pytest.mark.parametrize("dt,tol_max,tol_rms,tol_grad", [("f32", 1e-4, 1e-5, 2e-3), ("bf16", 0.1, 1e-2, 0.35)])
 def test_fused_launches_equal_separate_launches(tmp_path, dt, tol_max, tol_rms, tol_grad):
     """c64nb, batch 4: 64 / 32 / 16 wide scales (halo and no-halo strips of the fused depthwise kernel, the chained and
     the separate conv2 / conv0).  bf16 gradients: a last-bit difference of a float-atomic sum in the forward pass (GAP,
