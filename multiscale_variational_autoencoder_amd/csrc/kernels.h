@@ -166,7 +166,7 @@ void launch_upsample_bwd(const float* fine_grad, float* coarse_grad, int B, int 
 // per image: r, r_exp -> losses[b,0..1]; signs of the channel-mean terms -> sgn[b, 2*C]
 // also losses[b,2] = sum_s losses[b,3+s] (total KL)
 void launch_loss_fwd(const float* y, const float* recon, float* losses, int loss_stride, int nscales, float* sgn,
-                     int B, int H, int W, int C, hipStream_t s);
+                     int B, int H, int W, int C, hipStream_t s, float* scratch = nullptr, int64_t scratch_elems = 0);
 // du = clipmask(m) * (v1-v0)/2 * rf/B * (-sign(y-recon)/N - 0.5*(sgn_ch/(C*HW) + incrop*sgn_cc/(C*ncrop)))
 void launch_loss_bwd(const float* y, const float* recon, const float* merged, const float* sgn, float* du, int B,
                      int H, int W, int C, float v0, float v1, const float* hp, hipStream_t s);

@@ -1167,7 +1167,9 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
     }
     join_scales(h, s);
     merge_forward(h, B, h->recon, s);
-    launch_loss_fwd(xsrc, h->recon, h->losses, 3 + L, L, h->sgn, B, c.input_h, c.input_w, C, s);
+    // (partial sums of large images go through scale 0's first gradient scratch buffer: free until the backward pass)
+    launch_loss_fwd(xsrc, h->recon, h->losses, 3 + L, L, h->sgn, B, c.input_h, c.input_w, C, s, h->scales[0].scratch[0],
+                    h->scales[0].scratch_elems * (h->scales[0].bf ? 1 : 2) / 2 * (int64_t)h->cfg.max_batch);
     launch_metrics(h->losses, 3 + L, B, metrics, s);
     if (io->recon) (void)hipMemcpyAsync(io->recon, h->recon, sizeof(float) * hwC * B, hipMemcpyDeviceToDevice, s);
     if (io->losses)
