@@ -20,6 +20,15 @@ static inline int grid_for(int64_t n, int block = kBlock) {
 #define GRID_STRIDE(i, n)                                                                  \
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);                \
        i += (int64_t)gridDim.x * blockDim.x)
+// the same loop with the index type I of a kernel templated on it: uint32_t when the element count fits (the per-element
+// div / mod of the index then cost a few instructions instead of ~100 each for int64), int64_t otherwise
+#define GRID_STRIDE_T(I, i, n)                                                             \
+  for (I i = (I)blockIdx.x * (I)blockDim.x + (I)threadIdx.x; i < (I)(n); i += (I)gridDim.x * (I)blockDim.x)
+#define LAUNCH_IDX(n, KERNEL, ...)                                                         \
+  do {                                                                                     \
+    if ((n) < (int64_t)0x7FFFFFFF) hipLaunchKernelGGL(KERNEL<uint32_t>, __VA_ARGS__);      \
+    else hipLaunchKernelGGL(KERNEL<int64_t>, __VA_ARGS__);                                 \
+  } while (0)
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == ACT_RELU) return v > 0.f ? v : 0.f;
@@ -150,15 +159,16 @@ void launch_rng_keepmask(float* out, int64_t n, float p_drop, const uint64_t* se
 // ------------------------------------------------------------------------------------------------
 // input transform: normalize (:79-84), GaussianNoise (:139-142), SpatialDropout2D (:144-147)
 // ------------------------------------------------------------------------------------------------
+template <typename I>
 __global__ void k_prep(const float* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ keep,
                        float* __restrict__ out, int64_t n, int64_t per_img, int C, float v0, float inv_range2,
                        float noise_std, float keep_scale) {
-  GRID_STRIDE(i, n) {
+  GRID_STRIDE_T(I, i, n) {
     float v = (x[i] - v0) * inv_range2 - 1.0f;
     if (noise) v += noise[i] * noise_std;
     if (keep) {
-      int64_t b = i / per_img;
-      int c = (int)(i % C);
+      I b = i / (I)per_img;
+      int c = (int)(i % (I)C);
       v *= keep[b * C + c] * keep_scale;
     }
     out[i] = v;
@@ -168,8 +178,8 @@ void launch_prep(const float* x, const float* noise, const float* keep, float* o
                  float v0, float v1, float noise_std, float keep_scale, hipStream_t s) {
   ProfScope ps("pyramid", (double)(8.0*B*H*W*C), 0.0, s);
   int64_t per = (int64_t)H * W * C, n = per * B;
-  hipLaunchKernelGGL(k_prep, dim3(grid_for(n)), dim3(kBlock), 0, s, x, noise, keep, out, n, per, C, v0,
-                     2.0f / (v1 - v0), noise_std, keep_scale);
+  LAUNCH_IDX(n, k_prep, dim3(grid_for(n)), dim3(kBlock), 0, s, x, noise, keep, out, n, per, C, v0, 2.0f / (v1 - v0),
+             noise_std, keep_scale);
 }
 
 // _downsample_upsample (:292-315): f = G (*) in (3x3, zero SAME pad); band = in - f; down = f[::2, ::2]
@@ -1219,17 +1229,18 @@ void launch_upsample_add(const float* coarse, const float* fine_in, float* fine_
 }
 // adjoint of the x2 bilinear upsample: coarse pixel i gathers fine 2i-1..2i+2 with weights .25 .75 .75 .25,
 // clamped indices fold onto the border pixel.
+template <typename I>
 __global__ void k_upsample_bwd(const float* __restrict__ fg, float* __restrict__ cg, int B, int h, int w, int C) {
   const int H = 2 * h, W = 2 * w;
   const float wt[4] = {0.25f, 0.75f, 0.75f, 0.25f};
   int64_t n = (int64_t)B * h * w * C;
-  GRID_STRIDE(i, n) {
-    int c = (int)(i % C);
-    int64_t p = i / C;
-    int x = (int)(p % w);
-    p /= w;
-    int y = (int)(p % h);
-    int64_t b = p / h;
+  GRID_STRIDE_T(I, i, n) {
+    int c = (int)(i % (I)C);
+    I p = i / (I)C;
+    int x = (int)(p % (I)w);
+    p /= (I)w;
+    int y = (int)(p % (I)h);
+    int64_t b = (int64_t)(p / (I)h);
     const float* fp = fg + b * H * W * C + c;
     float acc = 0.f;
 #pragma unroll
@@ -1247,7 +1258,7 @@ __global__ void k_upsample_bwd(const float* __restrict__ fg, float* __restrict__
 void launch_upsample_bwd(const float* fine_grad, float* coarse_grad, int B, int h, int w, int C, hipStream_t s) {
   ProfScope ps("merge", (double)(20.0*B*h*w*C), 0.0, s);
   int64_t n = (int64_t)B * h * w * C;
-  hipLaunchKernelGGL(k_upsample_bwd, dim3(grid_for(n)), dim3(kBlock), 0, s, fine_grad, coarse_grad, B, h, w, C);
+  LAUNCH_IDX(4 * n, k_upsample_bwd, dim3(grid_for(n)), dim3(kBlock), 0, s, fine_grad, coarse_grad, B, h, w, C);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1399,6 +1410,7 @@ void launch_loss_fwd(const float* y, const float* recon, float* losses, int loss
   hipLaunchKernelGGL(k_loss_fwd, dim3(B), dim3(256), 0, s, y, recon, losses, loss_stride, nscales, sgn, H, W, C, cy0,
                      cy1, cx0, cx1);
 }
+template <typename I>
 __global__ void k_loss_bwd(const float* __restrict__ y, const float* __restrict__ r, const float* __restrict__ merged,
                            const float* __restrict__ sgn, float* __restrict__ du, int B, int H, int W, int C, float v0,
                            float v1, const float* __restrict__ hp, int cy0, int cy1, int cx0, int cx1) {
@@ -1406,13 +1418,13 @@ __global__ void k_loss_bwd(const float* __restrict__ y, const float* __restrict_
   const float rfb = hp[HP_RF_OVER_B];
   const float hw = (float)H * W, ncrop = (float)(cy1 - cy0) * (cx1 - cx0);
   const float half_range = (v1 - v0) * 0.5f;
-  GRID_STRIDE(i, n) {
-    int c = (int)(i % C);
-    int64_t p = i / C;
-    int x = (int)(p % W);
-    p /= W;
-    int yy = (int)(p % H);
-    int64_t b = p / H;
+  GRID_STRIDE_T(I, i, n) {
+    int c = (int)(i % (I)C);
+    I p = i / (I)C;
+    int x = (int)(p % (I)W);
+    p /= (I)W;
+    int yy = (int)(p % (I)H);
+    int64_t b = (int64_t)(p / (I)H);
     float v = (merged[i] + 1.0f) * half_range + v0;
     float g = 0.f;
     if (v >= v0 && v <= v1) {
@@ -1432,8 +1444,8 @@ void launch_loss_bwd(const float* y, const float* recon, const float* merged, co
   int cy0, cy1, cx0, cx1;
   crop_box(H, W, &cy0, &cy1, &cx0, &cx1);
   int64_t n = (int64_t)B * H * W * C;
-  hipLaunchKernelGGL(k_loss_bwd, dim3(grid_for(n)), dim3(kBlock), 0, s, y, recon, merged, sgn, du, B, H, W, C, v0, v1,
-                     hp, cy0, cy1, cx0, cx1);
+  LAUNCH_IDX(n, k_loss_bwd, dim3(grid_for(n)), dim3(kBlock), 0, s, y, recon, merged, sgn, du, B, H, W, C, v0, v1, hp, cy0,
+             cy1, cx0, cx1);
 }
 __global__ void __launch_bounds__(256) k_metrics(const float* __restrict__ losses, int ncol, int B,
                                                  float* __restrict__ metrics) {
