@@ -238,8 +238,8 @@ bool launch_dw_bwd_fused(const float* dt2, const float* t1, const float* t0, con
                          int W, int C, hipStream_t s, bool bf = false);
 // float32: conv2 of one MobileNetV3 block chained with conv0 of the next (kernels_mfma.hip: k_conv2_chain); false = not covered
 bool launch_conv2_chain(const float* X, const float* W, const float* bias, const float* gate, const float* residual,
-                        float* Y, const float* W2, const float* bias2, float* Y2, int64_t M, int64_t rows_per_image, int C,
-                        hipStream_t s);
+                        float* Y, const float* wm, const float* biasm, float* Ym, bool mid_transposed, const float* W2,
+                        const float* bias2, float* Y2, int64_t M, int64_t rows_per_image, int C, hipStream_t s);
 // bf16: conv2 of one MobileNetV3 block chained with conv0 of the next (k16_pw_chain), optionally through the 1x1
 // convolution 64 -> 32 between them (wm / biasm / outm; mid_transposed = Conv2DTranspose form); false = shape not covered
 bool launch16_pw_chain(const void* in, const float* w, const float* bias, const float* gate, const void* residual, void* out,

@@ -1449,11 +1449,17 @@ __global__ void __launch_bounds__(256, GR ? 2 : 4) k_conv0_tile(const float* __r
 // of the following block): Y = (X * gate) . W + bias + residual is stored (it is the next block's residual and a saved
 // tensor) and goes back into the LDS tile, where the four waves read it as the A operand of Y2 = relu(Y . W2 + bias2):
 // the next block's conv0 does not read Y from HBM (one tensor pass less per block).
+// MID: a 1x1 convolution 64 -> 32 (WTM: the Conv2DTranspose layout [out][in]) sits between the two blocks and the next
+// block is 32 wide: Ym = Y . Wm + bm (stored) and Y2 = relu(Ym . W2 + b2) [32 -> 32], both by the waves of column group 0
+// on their own 32 rows (Wm / W2 as B operands from LDS: [k][n], lanes along n).
+template <bool MID, bool WTM>
 __global__ void __launch_bounds__(256, 2) k_conv2_chain(const float* __restrict__ X, const float* __restrict__ W,
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ gate,
                                                                 const float* __restrict__ residual,
-                                                                float* __restrict__ Y, const float* __restrict__ W2,
+                                                                float* __restrict__ Y, const float* __restrict__ Wm,
+                                                                const float* __restrict__ biasm, float* __restrict__ Ym,
+                                                                const float* __restrict__ W2,
                                                                 const float* __restrict__ bias2, float* __restrict__ Y2,
                                                                 int64_t M, int64_t rows_per_image) {
   constexpr int C = 64;
@@ -1471,10 +1477,23 @@ __global__ void __launch_bounds__(256, 2) k_conv2_chain(const float* __restrict_
 #pragma unroll
   for (int t = 0; t < KH; ++t) breg[t] = W[(int64_t)(h * KH + t) * C + n0 + i];
   const float bz = bias ? bias[n0 + i] : 0.f;
-  float breg2[KH];
+  float breg2[MID ? 1 : KH];
+  __shared__ float sWm[MID ? 64 * 32 : 1], sW2[MID ? 32 * 32 : 1];   // MID: Wm[k][n] (64 x 32), W2[k][n] (32 x 32)
+  float bz2, bzm = 0.f;
+  if constexpr (MID) {
+    for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+      const int kk = idx >> 5, nn = idx & 31;
+      sWm[idx] = WTM ? Wm[nn * 64 + kk] : Wm[kk * 32 + nn];
+    }
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) sW2[idx] = W2[idx];
+    bzm = biasm ? biasm[i] : 0.f;
+    bz2 = bias2 ? bias2[i] : 0.f;
+    breg2[0] = 0.f;
+  } else {
 #pragma unroll
-  for (int t = 0; t < KH; ++t) breg2[t] = W2[(int64_t)(h * KH + t) * C + n0 + i];
-  const float bz2 = bias2 ? bias2[n0 + i] : 0.f;
+    for (int t = 0; t < KH; ++t) breg2[t] = W2[(int64_t)(h * KH + t) * C + n0 + i];
+    bz2 = bias2 ? bias2[n0 + i] : 0.f;
+  }
 #define SWZ1(r, c) ((r) * C + ((((c) >> 2) ^ ((r) & MASK)) << 2) + ((c) & 3))
   const int64_t ntiles = M / TR;
   const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
@@ -1546,6 +1565,65 @@ __global__ void __launch_bounds__(256, 2) k_conv2_chain(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) sX[SWZ1(rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + i)] = acc[r];
     __syncthreads();
+    if constexpr (MID) {
+      if (nw == 0) {                                       // wave-uniform: column group 0 carries the two narrow products
+        // Ym[32 rows][32] = Y . Wm + bm : k = h*32 + t (lane half h takes its 32 k), B = sWm[k][i]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int bq = 0; bq < NB; ++bq) {
+          f32x4 afr[QH];
+          float bfr[QH * 4];
+#pragma unroll
+          for (int q = 0; q < QH; ++q) {
+            afr[q] = reinterpret_cast<const f32x4*>(sX)[SWZ4(rw * 32 + i, h * (C4 / 2) + bq * QH + q)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bfr[q * 4 + e] = sWm[(h * KH + (bq * QH + q) * 4 + e) * 32 + i];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < QH; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], bfr[q * 4 + e], acc, 0, 0, 0);
+        }
+        float* pym = Ym + (row0 + 4 * h) * 32 + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[r] += bzm;
+          pym[((r & 3) + 8 * (r >> 2)) * 32] = acc[r];
+        }
+        // Ym -> columns 0..31 of this wave's own rows of the tile (only this wave reads them: wave-local ordering)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sX[SWZ1(rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, i)] = acc[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // Y2 = relu(Ym . W2 + b2): K = 32, lane half h takes k = 16 h .. 16 h + 15 (float4 chunks 4 h .. 4 h + 3)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+          f32x4 afr[4];
+          float bfr[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            afr[q] = reinterpret_cast<const f32x4*>(sX)[SWZ4(rw * 32 + i, h * 4 + q)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bfr[q * 4 + e] = sW2[(h * 16 + q * 4 + e) * 32 + i];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][e], bfr[q * 4 + e], acc, 0, 0, 0);
+        }
+        float* py2 = Y2 + (row0 + 4 * h) * 32 + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) py2[((r & 3) + 8 * (r >> 2)) * 32] = fmaxf(acc[r] + bz2, 0.f);
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
@@ -1564,6 +1642,7 @@ __global__ void __launch_bounds__(256, 2) k_conv2_chain(const float* __restrict_
     float* py2 = Y2 + (row0 + 4 * h) * C + n0 + i;
 #pragma unroll
     for (int r = 0; r < 16; ++r) py2[((r & 3) + 8 * (r >> 2)) * C] = fmaxf(acc[r] + bz2, 0.f);
+    }
   };
   // This block's tiles are tile, tile + g1, ...: `mine` of them.  They are processed in pairs by a loop with a FIXED trip
   // count and no exit in the middle (an early `break` between the two halves let LLVM sink the first half's prefetch
@@ -1606,17 +1685,24 @@ bool launch_conv0_tile(const float* X, const float* W, const float* bias, const 
   return true;
 }
 
-// conv2 of a block + conv0 of the next in one launch (k_conv2_chain).  false = shape not covered / switched off.
+// conv2 of a block + conv0 of the next in one launch (k_conv2_chain); with wm: through the 1x1 convolution 64 -> 32 between
+// them into a 32-wide block (mid_transposed: Conv2DTranspose weight layout).  false = shape not covered / switched off.
 bool launch_conv2_chain(const float* X, const float* W, const float* bias, const float* gate, const float* residual,
-                        float* Y, const float* W2, const float* bias2, float* Y2, int64_t M, int64_t rows_per_image, int C,
-                        hipStream_t s) {
+                        float* Y, const float* wm, const float* biasm, float* Ym, bool mid_transposed, const float* W2,
+                        const float* bias2, float* Y2, int64_t M, int64_t rows_per_image, int C, hipStream_t s) {
   static const bool on = [] { const char* e = getenv("MVAE_FUSE_PW_CHAIN"); return e ? atoi(e) != 0 : true; }();
   if (!on || C != 64 || !gate || !residual || rows_per_image % 16 != 0) return false;
   if (M % 64 != 0 || M < 256 * 64) return false;
   const int64_t ntiles = M / 64;
   const int cap = 2 * big_grid_cus();
   const int grid = (int)(ntiles < cap ? ntiles : cap);
-  hipLaunchKernelGGL(k_conv2_chain, dim3(grid), dim3(256), 0, s, X, W, bias, gate, residual, Y, W2, bias2, Y2, M, rows_per_image);
+#define MVAE_C2C(MID_, WT_)                                                                                          \
+  hipLaunchKernelGGL((k_conv2_chain<MID_, WT_>), dim3(grid), dim3(256), 0, s, X, W, bias, gate, residual, Y, wm, biasm, Ym, \
+                     W2, bias2, Y2, M, rows_per_image)
+  if (!wm) MVAE_C2C(false, false);
+  else if (mid_transposed) MVAE_C2C(true, true);
+  else MVAE_C2C(true, false);
+#undef MVAE_C2C
   return true;
 }
 

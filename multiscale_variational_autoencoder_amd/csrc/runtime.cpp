@@ -635,8 +635,15 @@ int mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipS
   }
   if (chain && chain->c == c && chain->H == m.H && chain->W == m.W) {
     ProfScope ps("k_conv2_chain", 16.0 * B * m.H * m.W * c, 4.0 * B * m.H * m.W * c * c, s);
-    if (launch_conv2_chain(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, P + chain->w0, P + chain->b0, chain->t0, M, HW, c, s))
+    if (launch_conv2_chain(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, nullptr, nullptr, nullptr, false, P + chain->w0,
+                           P + chain->b0, chain->t0, M, HW, c, s))
       return 1;
+  }
+  if (chain3 && c == 64 && chain3->mn.c == 32 && chain3->mn.H == m.H && chain3->mn.W == m.W) {
+    ProfScope ps("k_conv2_chain3", (12.0 + 4.0) * B * m.H * m.W * c, (2.0 * c * c + 2.0 * c * 32 + 2.0 * 32 * 32) * B * m.H * m.W, s);
+    if (launch_conv2_chain(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, P + chain3->cw, P + chain3->cb, chain3->cout,
+                           chain3_transposed, P + chain3->mn.w0, P + chain3->mn.b0, chain3->mn.t0, M, HW, c, s))
+      return 2;
   }
   bool tiled2;
   {
@@ -791,7 +798,7 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
     }
     Block* nb = &blk != &sc.dec.back() ? &blk + 1 : nullptr;
     MN* nextmn = (nb && !nb->has_conv) ? &nb->mn : nullptr;
-    Block* next3 = (sc.bf && nb && nb->has_conv && nb->cg.KH * nb->cg.KW == 1 && nb->cg.SH == 1 && nb->cg.SW == 1 &&
+    Block* next3 = (nb && nb->has_conv && nb->cg.KH * nb->cg.KW == 1 && nb->cg.SH == 1 && nb->cg.SW == 1 &&
                     nb->cg.CO == 64 && nb->cg.CI == 32) ? nb : nullptr;          // convT: CO = its input, CI = its output
     chained = mn_forward(h, blk.mn, x, B, training, s, sc.bf, nextmn, chained != 0, next3, true);
     x = blk.mn.out;
@@ -1143,7 +1150,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
         }
         Block* nb = &blk != &sc.enc.back() ? &blk + 1 : nullptr;
         MN* nextmn = (nb && !nb->has_conv) ? &nb->mn : nullptr;
-        Block* next3 = (sc.bf && nb && nb->has_conv && nb->cg.KH * nb->cg.KW == 1 && nb->cg.SH == 1 && nb->cg.SW == 1 &&
+        Block* next3 = (nb && nb->has_conv && nb->cg.KH * nb->cg.KW == 1 && nb->cg.SH == 1 && nb->cg.SW == 1 &&
                         nb->cg.CI == 64 && nb->cg.CO == 32) ? nb : nullptr;
         chained = mn_forward(h, blk.mn, x, B, training, ss, sc.bf, nextmn, chained != 0, next3, false);
         x = blk.mn.out;
