@@ -35,6 +35,9 @@ CONFIGS = {
     # the notebook blocks on a 24 x 40 image: widths 40 / 20 / 10 are not powers of two (the index-division paths of the
     # tiled conv kernels), 3 x 12 x 20 pixels do not fill the kernels' 128-pixel tiles, 40 columns need two ring strips
     "nbodd": dict(input_dims=(24, 40, 3), z_dims=[8, 8], encoder=NB, decoder=NB),
+    # the notebook blocks on a 96 x 64 image: heights 96 / 48 / 24 are not powers of two, the 64-wide maps take two ring
+    # strips (halo columns), the 32-wide ones one; rows per image 6144 / 1536 / 384 (the chained 1x1 launches need % 64)
+    "c96nb": dict(input_dims=(96, 64, 3), z_dims=[16, 16], encoder=NB, decoder=NB),
     # BASELINE configs 4-5 (C256-nb), full size: 7 scales from 256x256 down to 4x4
     "c256nb": dict(input_dims=(256, 256, 3), z_dims=[16] * 7, encoder=NB, decoder=NB),
 }

@@ -120,7 +120,7 @@ def _check(rep, tol_grad=TOL16_GRAD, tol_vec=TOL16_GRAD_VEC):
 
 # ("c64nb", 32): the scale-0 decoder then has 131072 rows per tensor, as many as C256-nb at batch 2 below
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("name,B,nbf", [("c32nb", 8, 2), ("c64nb", 2, 3), ("c64nb", 32, 3)])
+@pytest.mark.parametrize("name,B,nbf", [("c32nb", 8, 2), ("c64nb", 2, 3), ("c64nb", 32, 3), ("c96nb", 8, 2)])
 def test_bf16_forward_backward_parity(name, B, nbf):
     rep, eng = _report(name, B, nbf)
     if B == 2:
