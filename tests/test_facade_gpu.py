@@ -117,3 +117,30 @@ def test_train_on_batch_matches_one_oracle_step():
     # error measured against the size of the step (lr), as in test_adagrad_trajectory_parity
     worst = max(float(np.abs(w[k] - p[k]).max() / COMPILE["learning_rate"]) * (0.1 if k in zero else 1.0) for k in p)
     assert worst <= 3e-2, worst
+
+
+def test_bf16_facade_train_checkpoint_predict(tmp_path):
+    """The same notebook flow with act_dtype="bf16" on a 32x32 model whose scales run in bfloat16: trains (the loss
+    comes down), predicts in range, saves a checkpoint a float32 model of the same architecture loads (parameters are
+    float32 in both modes), and the two models then agree on the reconstruction within the bf16 forward bar."""
+    from multiscale_variational_autoencoder_amd import MultiscaleVAE
+    cfg = CONFIGS["c32nb"]
+    args = dict(input_dims=cfg["input_dims"], z_dims=cfg["z_dims"], encoder=cfg["encoder"], decoder=cfg["decoder"])
+    v = MultiscaleVAE(act_dtype="bf16", **args)
+    assert v._engine.scale_dtypes()[:2] == ["bf16", "bf16"]
+    v.compile(learning_rate=0.003, r_loss_factor=1000, kl_loss_factor=10)
+    rng = np.random.default_rng(4)
+    base = rng.uniform(0, 255, (256, 1, 1, 3))
+    x = np.clip(base + rng.normal(0, 20, (256, 32, 32, 3)), 0, 255).astype(np.float32)
+    hist = v.train(x, batch_size=64, epochs=3, run_folder=str(tmp_path), step_size=2, lr_decay=0.5,
+                   save_checkpoint_weights=True)
+    assert np.all(np.isfinite(hist.history["loss"])) and hist.history["loss"][-1] < hist.history["loss"][0]
+    recon = v.model_trainable.predict(x[:16], batch_size=16)
+    assert recon.shape == (16, 32, 32, 3) and recon.min() >= 0.0 and recon.max() <= 255.0
+    ck = sorted(glob.glob(os.path.join(str(tmp_path), "weights", "weights-*.npz")))[-1]
+    w = MultiscaleVAE(**args)                                # float32 activations, same parameters
+    w.compile(learning_rate=0.003, r_loss_factor=1000, kl_loss_factor=10)
+    w.load_weights(ck)
+    recon32 = w.model_trainable.predict(x[:16], batch_size=16)
+    d = recon.astype(np.float64) - recon32
+    assert np.sqrt((d ** 2).mean()) <= 1.5e-2 * 255 and np.abs(d).max() <= 0.15 * 255, (np.sqrt((d ** 2).mean()), np.abs(d).max())
