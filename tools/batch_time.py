@@ -1,3 +1,4 @@
+"""Median step time of the C32-nb train step at a given batch and activation dtype: python tools/batch_time.py B [f32|bf16]"""
 import sys, os, json
 import numpy as np
 sys.path.insert(0, "/root/repo")
@@ -6,7 +7,8 @@ from bench import NB
 from multiscale_variational_autoencoder_amd.engine import Engine
 from multiscale_variational_autoencoder_amd.initializers import init_params
 B = int(sys.argv[1])
-eng = Engine((32, 32, 3), [16] * 3, NB, NB, 0.0, 255.0, 0.01, B).bind(0)
+dt = sys.argv[2] if len(sys.argv) > 2 else "f32"
+eng = Engine((32, 32, 3), [16] * 3, NB, NB, 0.0, 255.0, 0.01, B, act_dtype=dt).bind(0)
 eng.set_params(init_params(eng.param_table, 42))
 x = eng.to_device(np.random.default_rng(1).uniform(0, 255, (B, 32, 32, 3)))
 for i in range(5):
@@ -20,4 +22,4 @@ for i in range(steps):
     evs[i + 1].record(eng.stream)
 torch.cuda.synchronize()
 per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
-print(B, float(np.median(per)))
+print(B, dt, float(np.median(per)), "ms/step", B / float(np.median(per)) * 1e3, "images/s")
