@@ -134,6 +134,135 @@ def timed_steps(eng, step, steps, torch, dist, world):
     return dt, per
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without an external launcher: the parent -- which never touches the GPU (no torch
+    import, no HIP call) -- starts `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a
+    child process, relays its output (rank 0 prints the one JSON line) and returns its exit code (torchrun's is non-zero
+    as soon as any rank's is)."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: self-launch: %s\n" % " ".join(cmd))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_profile(step, nprof, act, workload):
+    """`nprof` instrumented steps (HIP events around every launch, on the launch stream, scales one after another):
+    ({tag: {count, ms, bytes, flops, avg_us, share, GBps, TFLOPs}}, roofline block of the dominant kernel)."""
+    from multiscale_variational_autoencoder_amd import _abi
+    lib = _abi.load_library()
+    lib.mvae_profile_enable(1)
+    for i in range(nprof):
+        step(10_000 + i)
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.mvae_profile_report(buf, len(buf))
+    lib.mvae_profile_enable(0)
+    kernels = json.loads(buf.value.decode())
+    tot = sum(v["ms"] for v in kernels.values())
+    for v in kernels.values():
+        v["avg_us"] = 1e3 * v["ms"] / v["count"]
+        v["share"] = v["ms"] / tot
+        v["GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+        v["TFLOPs"] = v["flops"] / (v["ms"] * 1e-3) / 1e12
+    pmc = pmc_traffic_table(workload)
+    fam_alg, fam_n = {}, {}
+    for k, v in kernels.items():
+        fam_alg[k.split("@")[0]] = fam_alg.get(k.split("@")[0], 0.0) + v["bytes"]
+        fam_n[k.split("@")[0]] = fam_n.get(k.split("@")[0], 0) + v["count"]
+    for k, v in kernels.items():       # measured HBM bytes per launch (committed PMC passes) next to the algorithmic ones
+        fam = k.split("@")[0]          # size-bucketed tags (conv1x1_f@2^17 ...) share one rocprof kernel family: the
+        t = pmc_lookup(pmc[0], fam) if pmc else None       # PMC figure is then the family's launch-weighted mean
+        v["algorithmic_bytes_per_launch"] = v["bytes"] / v["count"]
+        v["hbm_bytes_per_launch_pmc"] = t if fam == k else None
+        v["traffic_ratio"] = None if t is None else t / max(fam_alg[fam] / fam_n[fam], 1.0)
+    dom = max(kernels, key=lambda k: kernels[k]["ms"])
+    d = kernels[dom]
+    bytes_per_launch = d["bytes"] / d["count"]
+    dur = d["ms"] * 1e-3 / d["count"]
+    peak_f = BF16_PEAK if act == "bf16" else FP32_PEAK
+    roofline = dict(kernel=dom, bound="hbm", achieved=bytes_per_launch / dur / 1e9, peak=HBM_PEAK / 1e9,
+                    unit="GB/s", frac=bytes_per_launch / dur / HBM_PEAK, traffic=d["hbm_bytes_per_launch_pmc"],
+                    traffic_source=None if not pmc or d["hbm_bytes_per_launch_pmc"] is None else
+                    "profiles/%s (separate rocprofv3 --pmc passes of this command, not this run)" % pmc[1],
+                    avg_launch_us=dur * 1e6, launches_per_step=d["count"] / nprof,
+                    algorithmic_bytes_per_launch=bytes_per_launch,
+                    flop_frac=d["flops"] / d["count"] / dur / peak_f, share_of_step=d["share"])
+    return kernels, roofline
+
+
+def pmc_traffic_table(workload):
+    """The newest committed rocprofv3 PMC summary of this workload (tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
+    separate passes, FETCH doubled per MI355X_MICROARCH.md), or None."""
+    for cand in ("round3_pmc_traffic_%s.json" % workload, "round2_pmc_traffic_%s.json" % workload):
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                return json.load(f), cand
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+# profiler tag -> rocprofv3 kernel-name prefixes it covers (a tag may cover several template instances)
+TAG_KERNELS = {"conv1x1_f": ["k_gemm_rows"], "conv1x1_t": ["k_gemm_rows"], "conv1x1_wgrad": ["k_wgrad_rows"],
+               "convkxk_f": ["k_conv_taps"], "convkxk_t": ["k_conv_taps"], "convkxk_wgrad": ["k_wgrad_taprow"],
+               "se_fwd": ["k_se_fwd1", "k_se_fwd2"], "se_bwd": ["k_se_bwd1", "k_se_bwd2"], "k_conv2_tile": ["k_conv0_tile<64, true>", "k_conv0_tile<32, true>"],
+               "k_conv0_tile": ["k_conv0_tile<64, false>", "k_conv0_tile<32, false>"], "k_conv2_chain": ["k_conv2_chain<false"],
+               "k_conv2_chain3": ["k_conv2_chain<true"], "head_fwd": ["k_head_fwd"], "head_bwd": ["k_head_bwd_reduce", "k_head_bwd_apply"],
+               "convbase_fwd": ["k_convbase_fwd_mfma"], "convbase_wgrad": ["k_convbase_wgrad_mfma"], "k_dw_fwd_img": ["k_dw_fwd_img"],
+               "k_dw_bwd_img": ["k_dw_bwd_img"], "k_mn_fwd_img": ["k_mn_fwd_img"], "k_mn_bwd_img": ["k_mn_bwd_img"]}
+
+
+def pmc_lookup(pmc, tag):
+    """HBM bytes per launch of profiler tag `tag`: launch-weighted mean over the kernels the tag covers."""
+    names = TAG_KERNELS.get(tag, [tag])
+    fam = [v for k, v in pmc.items() for n in names if k.replace("mvae::", "").startswith(n)]
+    if not fam and "<" not in tag:
+        fam = [v for k, v in pmc.items() if k.replace("mvae::", "").startswith(tag + "<")]
+    if not fam:
+        return None
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam) / sum(v["launches"] for v in fam)
+
+
+def secondary_workload(wname, local, torch, dist, lr, rf, kf, clip, profile=True, steps=10):
+    """One more workload of BASELINE.json beside the headline: {ms_per_step, images_per_sec, hbm_frac, roofline}."""
+    from multiscale_variational_autoencoder_amd.engine import Engine
+    from multiscale_variational_autoencoder_amd.initializers import init_params
+    w = WORKLOADS[wname]
+    B, act = w["batch"], w.get("dtype", "f32")
+    H, Wd, C = w["input_dims"]
+    e = Engine(w["input_dims"], w["z_dims"], w["encoder"], w["decoder"], 0.0, 255.0, 0.01, B, act_dtype=act).bind(local)
+    e.set_params(init_params(e.param_table, 42))
+    x = e.to_device(np.random.default_rng(77).uniform(0, 255, (B, H, Wd, C)))
+    st = lambda i: e.train_step(x, lr, rf, kf, clip, seed=9000 + i)
+    for i in range(3):
+        st(i)
+    dt, per = timed_steps(e, lambda i: st(100 + i), steps, torch, dist, 1)
+    nbytes = algorithmic_bytes_per_step(w, B, act)
+    out = {"workload": "%s: %dx%dx%d, %d scales, batch %d, %s activations" % (wname, H, Wd, C, len(w["z_dims"]), B, act),
+           "images_per_sec": B * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "ms_per_step_median_events": float(np.median(per)), "algorithmic_bytes_per_step": nbytes,
+           "hbm_frac": nbytes / (dt / steps) / HBM_PEAK, "scale_dtypes": e.scale_dtypes(),
+           "flop_frac": 3 * w["F"] * B / (dt / steps) / (BF16_PEAK if act == "bf16" else FP32_PEAK)}
+    m = e.metrics()
+    out["finite"] = bool(np.isfinite(m["r_exp"]) and np.isfinite(m["vae_kl_loss"]))
+    if profile:
+        kernels, out["roofline"] = kernel_profile(st, 2, act, wname)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_kernels_%s_%s_n1.json" % (wname, act)), "w") as f:
+            json.dump(kernels, f, indent=1, sort_keys=True)
+    e.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,13 +278,21 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
+    # debugging switches that change what a step computes must not be set for a measurement (the release library does not
+    # even compile MVAE_DEBUG_ONLY_SCALE in; MVAE_DEBUG_BUILD=1 at build time brings it back for tools/chain_only.py)
+    debug_env = sorted(k for k in os.environ if k.startswith("MVAE_DEBUG_"))
+    if debug_env:
+        raise SystemExit("bench.py refuses to run with debugging switches set: %s" % ", ".join(debug_env))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     # rehearsal of the N > 1 path on a one-GPU box (MVAE_BENCH_REHEARSE=gloo): every rank uses cuda:0 and the
     # all-reduce goes through gloo -- exercises rank handling, the all-reduce of the reduce arena and the JSON line,
     # not RCCL performance.  The driver's real runs use backend "nccl" (= RCCL), one rank per GPU.
@@ -210,6 +347,10 @@ def main():
             coll["note"] = "world 1 (--force-collective): the all-reduce is an in-place no-op, the figure is its launch cost"
     m = eng.metrics()
     finite = bool(np.isfinite(m["r_exp"]) and np.isfinite(m["vae_kl_loss"]))
+    coll_desc = ("none" if not collective else
+                 "2 RCCL all-reduces per step: %d floats (Dense-weight gradients) overlapped with the encoder "
+                 "half of the backward pass, then %d floats" % (eng.reduce_split, eng.R - eng.reduce_split)
+                 if eng.dp_overlap_active() else "1 RCCL all-reduce of %d floats per step" % eng.R)
     # "also report forward+backward+ELBO without the optimiser" (secondary number, single GPU only)
     fb_ms = None
     secondary = {}
@@ -227,49 +368,7 @@ def main():
     # ---- per-kernel durations, live, with HIP events on the launch stream (instrumented extra steps)
     roofline, kernels = None, None
     if not args.no_kernel_profile:
-        lib = _abi.load_library()
-        lib.mvae_profile_enable(1)
-        nprof = 3
-        for i in range(nprof):
-            step(10_000 + i)
-        buf = ctypes.create_string_buffer(1 << 16)
-        lib.mvae_profile_report(buf, len(buf))
-        lib.mvae_profile_enable(0)
-        kernels = json.loads(buf.value.decode())
-        tot = sum(v["ms"] for v in kernels.values())
-        for v in kernels.values():
-            v["avg_us"] = 1e3 * v["ms"] / v["count"]
-            v["share"] = v["ms"] / tot
-            v["GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
-            v["TFLOPs"] = v["flops"] / (v["ms"] * 1e-3) / 1e12
-        dom = max(kernels, key=lambda k: kernels[k]["ms"])
-        d = kernels[dom]
-        bytes_per_launch = d["bytes"] / d["count"]
-        dur = d["ms"] * 1e-3 / d["count"]
-        # HBM bytes per launch: NOT measured in this run -- taken from the committed rocprofv3 PMC passes (separate
-        # FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH doubled per MI355X_MICROARCH.md; tools/pmc_traffic.py)
-        traffic, traffic_source = None, None
-        for cand in ("round2_pmc_traffic_%s.json" % args.workload, "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", cand)) as f:
-                    pmc = json.load(f)
-            except (OSError, ValueError):
-                continue
-            t = pmc.get("mvae::" + dom, pmc.get(dom, {})).get("hbm_bytes_per_launch")
-            if t is None:          # a tag that covers several template instances (k16_pw): launch-weighted mean of them
-                fam = [v for k, v in pmc.items() if k.startswith("mvae::" + dom.split("<")[0] + "<")]
-                if fam and "<" not in dom:
-                    t = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam) / sum(v["launches"] for v in fam)
-            if t is not None and (cand.startswith("round2") or args.workload == "c32nb"):
-                traffic, traffic_source = t, "profiles/" + cand + " (separate rocprofv3 --pmc passes, not this run)"
-                break
-        peak_f = BF16_PEAK if act == "bf16" else FP32_PEAK
-        roofline = dict(kernel=dom, bound="hbm", achieved=bytes_per_launch / dur / 1e9, peak=HBM_PEAK / 1e9,
-                        unit="GB/s", frac=bytes_per_launch / dur / HBM_PEAK, traffic=traffic,
-                        traffic_source=traffic_source,
-                        avg_launch_us=dur * 1e6, launches_per_step=d["count"] / nprof,
-                        algorithmic_bytes_per_launch=bytes_per_launch,
-                        flop_frac=d["flops"] / d["count"] / dur / peak_f, share_of_step=d["share"])
+        kernels, roofline = kernel_profile(step, 3, act, args.workload)
 
     # BASELINE config 1 (C32-nb at batch 128, the reference's own notebook batch) on the GPU, next to the headline
     if world == 1 and args.workload == "c32nb" and not args.no_secondary and not args.batch:
@@ -297,6 +396,18 @@ def main():
                                                "hbm_frac": algorithmic_bytes_per_step(w, B, "bf16") / (dt3 / 30) / HBM_PEAK}
             e3.close()
 
+    # BASELINE config 4 (C256-nb, 7 scales, batch 64, bf16 activations) under the driver's default run: its own step time,
+    # roofline fraction and dominant-kernel block (about 2 s of GPU time; the headline engine is released first)
+    if world == 1 and args.workload == "c32nb" and not args.no_secondary and not args.batch and act == "f32":
+        eng.close()
+        del eng, x
+        torch.cuda.empty_cache()
+        try:
+            secondary["c256nb_b64_bf16"] = secondary_workload("c256nb", local, torch, dist, lr, rf, kf, clip,
+                                                              profile=not args.no_kernel_profile)
+        except Exception as e:        # never lose the headline line to the secondary one
+            secondary["c256nb_b64_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     ms = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
     step_bytes = algorithmic_bytes_per_step(w, B, act)
@@ -309,11 +420,8 @@ def main():
                                "train step incl. Adagrad, %s activations" % (args.workload, H, Wd, C, len(w["z_dims"]), w["z_dims"][0],
                                                             w["encoder"]["filters"], B, B * world, act),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "collective": ("none" if not collective else
-                                  "2 RCCL all-reduces per step: %d floats (Dense-weight gradients) overlapped with the encoder "
-                                  "half of the backward pass, then %d floats" % (eng.reduce_split, eng.R - eng.reduce_split)
-                                  if eng.dp_overlap_active() else "1 RCCL all-reduce of %d floats per step" % eng.R)},
-        "finite": finite,
+                   "collective": coll_desc},
+        "finite": finite, "debug_env": debug_env,
         "timing": {"ms_per_step_median_events": med, "ms_per_step_min_events": float(per_step.min()),
                    "ms_per_step_p90_events": float(np.percentile(per_step, 90)),
                    "images_per_sec_median_events": B * world / (med * 1e-3),

@@ -97,6 +97,9 @@ int mvae_create(const mvae_config* cfg, mvae_handle** out);
 void mvae_destroy(mvae_handle* h);
 const char* mvae_last_error(const mvae_handle* h);      /* h may be NULL: error of the last failed create */
 int mvae_abi_version(void);
+/* 1 when the library was built with -DMVAE_DEBUG_BUILD (timing-diagnostic switches such as MVAE_DEBUG_ONLY_SCALE are
+ * compiled in: results may then be garbage on request); 0 for the release build, which contains none of them. */
+int mvae_debug_build(void);
 
 /* ---- tables: the layer/variable inventory Keras builds ---- */
 int64_t mvae_param_count(const mvae_handle* h);         /* number of trainable tensors            */

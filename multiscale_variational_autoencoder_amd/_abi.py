@@ -46,6 +46,7 @@ class MvaeStepIO(C.Structure):
 _H = C.c_void_p
 SYMBOLS = {
     "mvae_abi_version": (C.c_int, []),
+    "mvae_debug_build": (C.c_int, []),
     "mvae_create": (C.c_int, [C.POINTER(MvaeConfig), C.POINTER(_H)]),
     "mvae_destroy": (None, [_H]),
     "mvae_last_error": (C.c_char_p, [_H]),

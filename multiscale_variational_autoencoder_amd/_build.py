@@ -36,6 +36,8 @@ def build(force=False, verbose=False):
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 os.path.getmtime(src), *[os.path.getmtime(os.path.join(CSRC, hd)) for hd in HEADERS]):
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", src, "-o", obj]
+            if os.environ.get("MVAE_DEBUG_BUILD", "") == "1":     # timing-diagnostic switches (runtime.cpp); never the default
+                cmd.insert(1, "-DMVAE_DEBUG_BUILD")
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)

@@ -75,6 +75,7 @@ class SaveIntermediateResultsCallback:
     def __init__(self, run_folder, print_every_n_batches, initial_epoch, images, vae, resize_shape=(256, 256)):
         self._vae = vae
         self._images = np.asarray(images, np.float32)
+        self.predict_batch = int(self._images.shape[0])     # fit() sizes the engine for this (no mid-epoch re-plan)
         self._epoch = initial_epoch
         self._run_folder = run_folder
         self._resize_shape = resize_shape

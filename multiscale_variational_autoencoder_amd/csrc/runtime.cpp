@@ -252,10 +252,19 @@ bool scale_bf16_ok(const mvae_config& c, int H, int W) {
         const bool pw = kh[i] == 1 && kw[i] == 1 && sh[i] == 1 && sw[i] == 1;
         const bool pair = (ch == 32 && f[i] == 64) || (ch == 64 && f[i] == 32);
         if (!pair) return false;
-        if (!pw && !(kw[i] == 5 && kh[i] <= 8)) return false;
+        // a k x k layer runs F-form in one direction and T-form in the other, plus the weight-gradient kernel: the
+        // launcher predicates of all three (kernels_bf16.hip: launch16_taps / launch16_wgrad) must hold, or the scale
+        // stays float32 -- kernel row count, taps per sub-pixel phase, 32-bit byte offsets into both tensors at max_batch
+        const int bh = hh, bw = ww, bc = ch;             // the side this walk comes from
         if (dec) { hh *= sh[i]; ww *= sw[i]; }
         else { int o, p; same_pad(hh, kh[i], sh[i], &o, &p); hh = o; same_pad(ww, kw[i], sw[i], &o, &p); ww = o; }
         ch = f[i];
+        if (!pw) {
+          if (kw[i] != 5 || kh[i] > 8 || kh[i] * kw[i] > 25) return false;
+          if (((kh[i] + sh[i] - 1) / sh[i]) * ((kw[i] + sw[i] - 1) / sw[i]) > 9) return false;
+          const int64_t lim = 1LL << 31;
+          if ((int64_t)c.max_batch * bh * bw * bc * 2 >= lim || (int64_t)c.max_batch * hh * ww * ch * 2 >= lim) return false;
+        }
       }
       if (!map_ok(hh, ww, ch)) return false;
     }
@@ -851,11 +860,17 @@ hipStream_t scale_stream(mvae_handle* h, int scale, hipStream_t main) {
   return h->side[h->merge_side ? 1 : scale];
 }
 // TIMING DIAGNOSTIC ONLY (tools/chain_only.py): MVAE_DEBUG_ONLY_SCALE=k launches the kernels of scale k alone -- the
-// results are then garbage; it prices one scale's chain without the others beside it.
+// results are then garbage; it prices one scale's chain without the others beside it.  The release library does not
+// contain the switch: it exists only in a build made with MVAE_DEBUG_BUILD=1 (_build.py adds -DMVAE_DEBUG_BUILD), and
+// mvae_debug_build() tells a caller (bench.py, the tests) which of the two it has loaded.
+#ifdef MVAE_DEBUG_BUILD
 bool debug_skip_scale(int si) {
   static const int only = [] { const char* e = getenv("MVAE_DEBUG_ONLY_SCALE"); return e ? atoi(e) : -1; }();
   return only >= 0 && si != only;
 }
+#else
+constexpr bool debug_skip_scale(int) { return false; }
+#endif
 void fork_scales(mvae_handle* h, hipStream_t main) {
   if (serial_scales(h)) return;
   (void)hipEventRecord(h->ev_fork, main);
@@ -888,6 +903,10 @@ int run_captured(mvae_handle* h, const std::string& key, hipStream_t s, const st
     }
     body(s);
     hipError_t e = hipStreamEndCapture(s, &graph);
+    if (h->kernel_gap) {                  // a launch sequence with a missing kernel is never cached (nor replayed)
+      if (graph) (void)hipGraphDestroy(graph);
+      return fail(h, MVAE_E_INVALID, "%s: a bfloat16 launch found no kernel for its shape", key.c_str());
+    }
     hipGraphExec_t exec = nullptr;
     if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (graph) (void)hipGraphDestroy(graph);
@@ -921,6 +940,14 @@ int check_launch(mvae_handle* h, const char* what) {
 extern "C" {
 
 int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
+
+int mvae_debug_build(void) {
+#ifdef MVAE_DEBUG_BUILD
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 const char* mvae_last_error(const mvae_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -1083,6 +1110,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
   hipStream_t s0 = static_cast<hipStream_t>(stream);
   const bool training = io->training != 0;
   const float* P = h->dp;
+  h->kernel_gap = false;                   // per call: an earlier failed call must not poison the handle
   const int64_t hwC = (int64_t)c.input_h * c.input_w * C;
   float* metrics = h->dr + h->P + h->S;
   const mvae_step_io io_c = *io;
@@ -1202,6 +1230,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
   hipStream_t s0 = static_cast<hipStream_t>(stream);
   const float* P = h->dp;
   float* G = h->dr;
+  h->kernel_gap = false;
   // loss factors go through the device hyper-parameter block: the captured graph does not depend on their values
   launch_set_f3(h->d_hp + HP_RF_OVER_B, r_factor / (float)B, kl_factor / (float)B, 0.f, 2, s0);
   // phase bit 1: loss, decoder halves, Dense gradients (everything that fills the leading arena region);
@@ -1335,6 +1364,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
       launch_gemm_nt(sc.dmu, P + sc.mu_w, d, B, (int)sc.K, sc.z, nullptr, 0, s);
       launch_gemm_nt(sc.dlv, P + sc.lv_w, d, B, (int)sc.K, sc.z, nullptr, 1, s);
     }
+    if (!(bits & 2)) wgrad_join(h, sc, s);     // phase 0 ends here: its side-stream Dense gradients must be final
     sc.d_mid = d;
     }   // decoder half
     if (!(bits & 2)) return;
@@ -1464,12 +1494,14 @@ int mvae_decode(mvae_handle* h, const float* z, int32_t batch, float* recon, voi
   const mvae_config& c = h->cfg;
   if (batch <= 0 || batch > c.max_batch) return fail(h, MVAE_E_INVALID, "batch %d outside [1, %d]", batch, c.max_batch);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  h->kernel_gap = false;
   for (Scale& sc : h->scales) {
     launch_copy_cols(z, (int)h->Z, sc.z_off, sc.zs, sc.z, 0, batch, sc.z, s);
     decoder_forward(h, sc, batch, false, s);
   }
   merge_forward(h, batch, recon, s);
   h->last_B = 0;   // activations no longer belong to a training forward
+  if (h->kernel_gap) return fail(h, MVAE_E_INVALID, "mvae_decode: a bfloat16 launch found no kernel for its shape");
   return check_launch(h, "mvae_decode");
 }
 

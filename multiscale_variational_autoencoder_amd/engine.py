@@ -221,12 +221,11 @@ class Engine:
         return cap.value, eager.value
 
     def dp_overlap_active(self):
-        """Split the gradient exchange when the Dense-weight region is worth a collective of its own (>= 8 MB: the
-        256x256 configurations, 137 of 144 MB); MVAE_DP_OVERLAP=1 / 0 forces it on / off."""
-        env = os.environ.get("MVAE_DP_OVERLAP", "")
-        if env in ("0", "1"):
-            return env == "1" and self.reduce_split > 0
-        return self.reduce_split * 4 >= (8 << 20)
+        """Opt-in (MVAE_DP_OVERLAP=1): split the gradient exchange in two messages, the leading Dense-weight region of the
+        arena (137 of 144 MB for the 256x256 configurations) travelling while the encoder half of the backward pass still
+        runs.  OFF by default: no multi-GPU RCCL run has yet shown it bitwise-equal to the single-message path and faster
+        (it has only run over gloo on one GPU and over RCCL at world size 1, where the all-reduce is a no-op)."""
+        return os.environ.get("MVAE_DP_OVERLAP", "") == "1" and self.reduce_split > 0
 
     def apply(self, lr, clip_norm, grad_scale=1.0):
         self._check(self.lib.mvae_apply_adagrad(self.h, float(lr), float(clip_norm if clip_norm else 0.0),
@@ -310,7 +309,8 @@ class Engine:
         it stays on the host and batches travel through two pinned buffers with asynchronous H2D copies on a copy stream
         (the gather then runs on the host into the pinned buffer)."""
         torch = self.torch
-        x = np.ascontiguousarray(x, dtype=np.float32)
+        if not (isinstance(x, np.ndarray) and x.dtype == np.float32 and x.flags.c_contiguous):
+            x = np.ascontiguousarray(x, dtype=np.float32)     # (no host copy when the caller's array already fits)
         if tuple(x.shape[1:]) != self.input_dims:
             raise ValueError("dataset must be [N,%d,%d,%d]" % self.input_dims)
         free, _ = torch.cuda.mem_get_info(self.device)

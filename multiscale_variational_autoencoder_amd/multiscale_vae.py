@@ -289,7 +289,12 @@ class MultiscaleVAE:
         if n == 0:
             return hist
         per_max = -(-min(batch_size, n) // world)
-        eng = self._ensure_engine(per_max)
+        # callbacks predict on a handful of images (the intermediate-results callback: 16) between training steps: size the
+        # engine for them up front, or the first such call would re-plan and re-bind it mid-epoch (every captured graph and
+        # the resident dataset dropped and rebuilt)
+        need = max([per_max] + [int(getattr(cb, "predict_batch", 0)) for cb in callbacks])
+        fed = None
+        eng = self._ensure_engine(need)
         eng.load_dataset(x)
         for epoch in range(initial_epoch, epochs):
             for cb in callbacks:
@@ -301,9 +306,10 @@ class MultiscaleVAE:
             t0 = time.time()
             acc, seen, fed = None, 0, None
             for bi, (off, cnt) in enumerate(spans):
-                eng = self._ensure_engine(per_max)
+                eng = self._ensure_engine(need)
                 if fed is not eng:                              # first batch, or a callback re-bound the engine
                     if eng.dataset is None:
+                        fed = None                              # drop the old engine (and its resident dataset) first
                         eng.load_dataset(x)
                     eng.set_permutation(local)
                     fed = eng

@@ -98,3 +98,38 @@ def test_missing_library_fails_loudly(tmp_path):
     from multiscale_variational_autoencoder_amd import _abi
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _abi.load_library(str(tmp_path / "libmvae_hip.so"))
+
+
+def test_release_build_has_no_debug_switches(hip_lib):
+    """MVAE_DEBUG_ONLY_SCALE (a work-skipping timing diagnostic) exists only in -DMVAE_DEBUG_BUILD libraries."""
+    assert hip_lib.mvae_debug_build() == 0
+    out = subprocess.run(["strings", "-a", os.path.join(ROOT, "multiscale_variational_autoencoder_amd", "libmvae_hip.so")],
+                         capture_output=True, text=True, check=True).stdout
+    assert "MVAE_DEBUG_ONLY_SCALE" not in out
+
+
+def test_bf16_scale_decision_mirrors_the_launchers(hip_lib):
+    """A scale runs bfloat16 only when every bf16 launcher covers its shapes (scale_bf16_ok admitted 5x5
+    stride-1 layers and tensors >= 2 GiB, which launch16_taps / launch16_wgrad then refused at run time)."""
+    from multiscale_variational_autoencoder_amd.engine import Engine
+    nb = {"filters": [64, 64, 32], "kernel_size": [(5, 5), (3, 3), (1, 1)], "strides": [(2, 2), (1, 1), (1, 1)]}
+    eng = Engine((64, 64, 3), [8, 8], nb, nb, 0.0, 255.0, 0.01, 4, act_dtype="bf16")
+    assert eng.scale_dtypes() == ["bf16", "bf16"]
+    eng.close()
+    # 5x5 at stride 1: ceil(5/1)^2 = 25 taps per sub-pixel phase > 9 -> T-form has no kernel -> the scale stays float32
+    s1 = {"filters": [64, 64, 32], "kernel_size": [(5, 5), (3, 3), (1, 1)], "strides": [(1, 1), (1, 1), (1, 1)]}
+    eng = Engine((64, 64, 3), [8, 8], s1, s1, 0.0, 255.0, 0.01, 4, act_dtype="bf16")
+    assert eng.scale_dtypes() == ["f32", "f32"]
+    eng.close()
+    # kernel rows: 6..8 x 5 exceed the 25 taps the launchers stage
+    k7 = {"filters": [64, 64, 32], "kernel_size": [(7, 5), (3, 3), (1, 1)], "strides": [(2, 2), (1, 1), (1, 1)]}
+    eng = Engine((64, 64, 3), [8, 8], k7, k7, 0.0, 255.0, 0.01, 4, act_dtype="bf16")
+    assert eng.scale_dtypes() == ["f32", "f32"]
+    eng.close()
+    # 32-bit byte offsets: 256x256x64 bf16 at max_batch 256 is 2 GiB -> scale 0 float32, the smaller scales bfloat16
+    big = Engine((256, 256, 3), [16] * 7, nb, nb, 0.0, 255.0, 0.01, 256, act_dtype="bf16")
+    assert big.scale_dtypes()[0] == "f32" and big.scale_dtypes()[1] == "bf16"
+    big.close()
+    ok = Engine((256, 256, 3), [16] * 7, nb, nb, 0.0, 255.0, 0.01, 64, act_dtype="bf16")
+    assert ok.scale_dtypes()[0] == "bf16"
+    ok.close()
