@@ -100,6 +100,14 @@ int mvae_abi_version(void);
 /* 1 when the library was built with -DMVAE_DEBUG_BUILD (timing-diagnostic switches such as MVAE_DEBUG_ONLY_SCALE are
  * compiled in: results may then be garbage on request); 0 for the release build, which contains none of them. */
 int mvae_debug_build(void);
+/* The float32 5x5 stride-2 convolutions run as split-bf16 products on the bf16 matrix cores (csrc/kernels_split.hip:
+ * float32 accuracy, 2.7x the float32-MFMA rate).  0 = switched off (MVAE_SPLIT_CONV=0), 1 = in use, 2 = disabled for this
+ * process by the hardware self-test the first mvae_bind runs (a board on which a kernel running beside them returned
+ * wrong values keeps the float32-MFMA kernels). */
+int mvae_split_conv_status(void);
+/* What the self-test measured about the hardware erratum the build works around (no packed-float32 instructions in any
+ * kernel): the number of wrong values its check kernel returned when written with v_pk_fma_f32; -1 = self-test not run. */
+int mvae_split_conv_erratum(void);
 
 /* ---- tables: the layer/variable inventory Keras builds ---- */
 int64_t mvae_param_count(const mvae_handle* h);         /* number of trainable tensors            */

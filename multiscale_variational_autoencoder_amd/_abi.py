@@ -47,6 +47,8 @@ _H = C.c_void_p
 SYMBOLS = {
     "mvae_abi_version": (C.c_int, []),
     "mvae_debug_build": (C.c_int, []),
+    "mvae_split_conv_status": (C.c_int, []),
+    "mvae_split_conv_erratum": (C.c_int, []),
     "mvae_create": (C.c_int, [C.POINTER(MvaeConfig), C.POINTER(_H)]),
     "mvae_destroy": (None, [_H]),
     "mvae_last_error": (C.c_char_p, [_H]),

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmvae_hip.so")
-SOURCES = ["kernels_generic.hip", "kernels_mfma.hip", "kernels_opt.hip", "kernels_edge.hip", "kernels_dw.hip", "kernels_dense.hip", "kernels_se.hip", "kernels_bf16.hip", "dispatch.hip", "runtime.cpp"]
+SOURCES = ["kernels_generic.hip", "kernels_mfma.hip", "kernels_opt.hip", "kernels_edge.hip", "kernels_dw.hip", "kernels_dense.hip", "kernels_se.hip", "kernels_bf16.hip", "kernels_split.hip", "dispatch.hip", "runtime.cpp"]
 HEADERS = ["kernels.h", "act16.h", "prof.h", os.path.join("..", "..", "include", "mvae_hip.h")]
 
 
@@ -36,6 +36,12 @@ def build(force=False, verbose=False):
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 os.path.getmtime(src), *[os.path.getmtime(os.path.join(CSRC, hd)) for hd in HEADERS]):
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", src, "-o", obj]
+            # No packed-float32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in any kernel: on MI355X a
+            # v_pk_fma_f32 of one wave returns wrong values now and then while another wave of the same SIMD interleaves
+            # float32 VALU work with v_mfma_f32_32x32x16_bf16 -- which is what the split-bf16 convolutions do
+            # (csrc/kernels_split.hip, "Hardware self-test").  MVAE_PACKED_F32=1 builds with them.
+            if os.environ.get("MVAE_PACKED_F32", "") != "1":
+                cmd[1:1] = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Wno-unknown-attributes"]
             if os.environ.get("MVAE_DEBUG_BUILD", "") == "1":     # timing-diagnostic switches (runtime.cpp); never the default
                 cmd.insert(1, "-DMVAE_DEBUG_BUILD")
             if verbose:

@@ -268,4 +268,15 @@ bool launch_dense_wgrad_dec(const float* z, const float* dy, float* dW, float* d
                             bool bf = false);
 void launch_add_vec2(float* o0, const float* a0, float* o1, const float* a1, int n, hipStream_t s);
 
+// ---- float32 k x k convolutions as split-bf16 products on the bf16 matrix cores (kernels_split.hip) ----
+// x = x1 + x2 + x3 (three exact bf16 pieces), six bf16 MFMAs per product: float32 accuracy at 2.7x the f32-MFMA rate.
+bool split_conv_covers(const ConvGeom& g);                     // 5x5-like layers between 32 and 64 channels
+int64_t split_planes_bytes(const ConvGeom& g);                 // workspace for one layer's weight planes (both forms)
+void launch_split_weights(const float* W, void* planes, const ConvGeom& g, hipStream_t s);   // once per layer and step
+bool split_selftest();                 // first call: run the kernels next to a self-checking VALU kernel (see kernels_split.hip)
+int split_conv_erratum_count();        // wrong values the v_pk_fma_f32 form of the self-test's check kernel returned (-1: not run)
+int split_conv_status();               // 0 switched off (MVAE_SPLIT_CONV=0), 1 in use, 2 disabled by the self-test on this board
+bool launch_conv_taps_split(bool transposed, const float* in, const void* planes, const float* bias, float* out,
+                            const ConvGeom& g, hipStream_t s);
+
 }  // namespace mvae

@@ -63,6 +63,7 @@ struct Block {
   ConvGeom cg{};          // F-form coordinates (big = high-res side)
   int64_t cw = 0, cb = 0;
   float* cout = nullptr;  // conv / convT output
+  float* wsplit = nullptr; // bf16 planes of the k x k weights (kernels_split.hip), refreshed by every forward pass
   MN mn;
 };
 struct Scale {
@@ -377,6 +378,7 @@ int build_plan(mvae_handle* h) {
         blk.cb = b.param(bp + ".conv.b", {f}, 0);
         hh = g.OH; ww = g.OW; ch = f;
         blk.cout = as_ptr(b.actw(bp + ".conv", (int64_t)hh * ww * ch, sc.bf));
+        if (!sc.bf && split_conv_covers(g)) blk.wsplit = as_ptr(b.ws_alloc((split_planes_bytes(g) + 3) / 4));
       }
       build_mn(b, blk.mn, bp + ".mn", f, hh, ww, sc);
       sc.enc.push_back(blk);
@@ -409,6 +411,7 @@ int build_plan(mvae_handle* h) {
         blk.cb = b.param(bp + ".convT.b", {f}, 0);
         hh = g.IH; ww = g.IW; ch = f;
         blk.cout = as_ptr(b.actw(bp + ".convT", (int64_t)hh * ww * ch, sc.bf));
+        if (!sc.bf && split_conv_covers(g)) blk.wsplit = as_ptr(b.ws_alloc((split_planes_bytes(g) + 3) / 4));
       }
       build_mn(b, blk.mn, bp + ".mn", f, hh, ww, sc, i == c.dec_n - 1);
       sc.dec.push_back(blk);
@@ -498,8 +501,8 @@ void rebase_all(mvae_handle* h) {
     rb(sc.pcur);
     if (alias_band) sc.band = sc.pcur; else rb(sc.band);
     rb(sc.e0);
-    for (Block& b : sc.enc) { rb(b.cout); rb_mn(b.mn); }
-    for (Block& b : sc.dec) { rb(b.cout); rb_mn(b.mn); }
+    for (Block& b : sc.enc) { rb(b.cout); rb(b.wsplit); rb_mn(b.mn); }
+    for (Block& b : sc.dec) { rb(b.cout); rb(b.wsplit); rb_mn(b.mn); }
     rb(sc.mu); rb(sc.lv); rb(sc.zs); rb(sc.d0);
     rb(sc.bn_sum); rb(sc.bn_sqdev); rb(sc.bn_mean); rb(sc.bn_invstd); rb(sc.bn_scale); rb(sc.bn_shift);
     rb(sc.bn_sum_d); rb(sc.bn_sum_dx); rb(sc.head_S);
@@ -582,6 +585,23 @@ ConvGeom geom1x1(int B, int H, int W, int ci, int co) {
   g.B = B; g.IH = g.OH = H; g.IW = g.OW = W; g.CI = ci; g.CO = co;
   g.KH = g.KW = g.SH = g.SW = 1; g.PT = g.PL = 0;
   return g;
+}
+
+// k x k convolution of a float32 scale: split-bf16 kernel when the layer has weight planes, else the float32-MFMA / generic
+// path.  `refresh`: split the weights first (the forward passes; the backward pass reuses the planes of its forward).
+void conv_kxk(mvae_handle* h, Block& blk, bool transposed, bool refresh, const float* in, const float* bias, float* out,
+              const ConvGeom& g, hipStream_t s) {
+  const float* P = h->dp;
+  PreOp none{nullptr, nullptr, nullptr};
+  if (blk.wsplit) {
+    const double nb = (double)g.B * g.IH * g.IW * g.CI, ns = (double)g.B * g.OH * g.OW * g.CO;
+    ProfScope ps(transposed ? "k_conv_taps_s<T>" : "k_conv_taps_s<F>", 4.0 * (nb + ns + (double)g.KH * g.KW * g.CI * g.CO),
+                 2.0 * ns * g.KH * g.KW * g.CI, s);
+    if (refresh) launch_split_weights(P + blk.cw, blk.wsplit, g, s);
+    if (launch_conv_taps_split(transposed, in, blk.wsplit, bias, out, g, s)) return;
+  }
+  if (transposed) launch_conv_t(in, P + blk.cw, bias, nullptr, out, g, s);
+  else launch_conv_f(in, P + blk.cw, bias, nullptr, out, g, none, ACT_NONE, s);
 }
 
 // ---- MobileNetV3 block (layer_blocks.py:556-648 with squeeze_excite_block :418-462) ----------
@@ -801,7 +821,7 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
           if (c0) chained = 1;
         }
       } else {
-        launch_conv_t(x, P + blk.cw, P + blk.cb, nullptr, blk.cout, g, s);
+        conv_kxk(h, blk, true, true, x, P + blk.cb, blk.cout, g, s);
       }
       x = blk.cout;
     }
@@ -940,6 +960,9 @@ int check_launch(mvae_handle* h, const char* what) {
 extern "C" {
 
 int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
+
+int mvae_split_conv_status(void) { return split_conv_status(); }
+int mvae_split_conv_erratum(void) { return split_conv_erratum_count(); }
 
 int mvae_debug_build(void) {
 #ifdef MVAE_DEBUG_BUILD
@@ -1095,6 +1118,14 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipDeviceSynchronize();
+  {   // a plan with split-bf16 convolutions: once per process, check that this board runs them cleanly (kernels_split.hip)
+    bool wants = false;
+    for (Scale& sc : h->scales) {
+      for (Block& b : sc.enc) wants = wants || b.wsplit;
+      for (Block& b : sc.dec) wants = wants || b.wsplit;
+    }
+    if (wants && e == hipSuccess) (void)split_selftest();
+  }
   if (e != hipSuccess) return fail(h, MVAE_E_HIP, "bind: %s", hipGetErrorString(e));
   h->bound = true;
   return MVAE_OK;
@@ -1172,7 +1203,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
                                                         (int64_t)B * cg.IH * cg.IW, (int64_t)cg.IH * cg.IW, cg.CI, cg.CO, ACT_NONE, ss));
             else need16(h, launch16_taps(false, x, P + blk.cw, P + blk.cb, blk.cout, cg, ss));
           } else {
-            launch_conv_f(x, P + blk.cw, P + blk.cb, nullptr, blk.cout, cg, none, ACT_NONE, ss);
+            conv_kxk(h, blk, false, true, x, P + blk.cb, blk.cout, cg, ss);
           }
           x = blk.cout;
         }
@@ -1309,7 +1340,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
                                                       (int64_t)g.IH * g.IW, g.CI, g.CO, ACT_NONE, s));
           else need16(h, launch16_taps(false, d, P + blk.cw, nullptr, n, g, s));
         } else {
-          launch_conv_f(d, P + blk.cw, nullptr, nullptr, n, g, none, ACT_NONE, s);
+          conv_kxk(h, blk, false, false, d, nullptr, n, g, s);
         }
         release(sc, d);
         d = n;
@@ -1390,7 +1421,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
                                                       (int64_t)g.IH * g.IW, g.CO, g.CI, ACT_NONE, s));
           else need16(h, launch16_taps(true, d, P + blk.cw, nullptr, n, g, s));
         } else {
-          launch_conv_t(d, P + blk.cw, nullptr, nullptr, n, g, s);
+          conv_kxk(h, blk, true, false, d, nullptr, n, g, s);
         }
         release(sc, d);
         d = n;

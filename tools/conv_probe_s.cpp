@@ -1,0 +1,54 @@
+// Times the split-bf16 5x5 kernels (kernels_split.hip) next to the float32-MFMA ones (kernels_mfma.hip) on the headline
+// geometry, and reports their difference on random data:   conv_probe_s <batch>
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../multiscale_variational_autoencoder_amd/csrc/kernels.h"
+namespace mvae { bool launch_conv_taps_mfma(bool transposed, const float* in, const float* w, const float* bias, float* out,
+                           const ConvGeom& g, hipStream_t s); }
+using namespace mvae;
+static float* dev_rand(size_t n, float scale, unsigned seed) {
+  std::vector<float> h(n);
+  srand(seed);
+  for (auto& v : h) v = ((rand() / (float)RAND_MAX) - 0.5f) * 2.f * scale;
+  float* d; hipMalloc(&d, n * 4); hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice);
+  return d;
+}
+int main(int argc, char** argv) {
+  const int nb = argc > 1 ? atoi(argv[1]) : 512;
+  for (int cfg = 0; cfg < 4; ++cfg) {
+    const int ci = cfg < 2 ? 32 : 64, co = cfg < 2 ? 64 : 32, tr = cfg & 1;
+    ConvGeom g{nb, 32, 32, ci, 16, 16, co, 5, 5, 2, 2, 1, 1};
+    const size_t nbig = (size_t)nb * 32 * 32 * ci, nsm = (size_t)nb * 16 * 16 * co;
+    float* big = dev_rand(nbig, 1.f, 1); float* small = dev_rand(nsm, 1.f, 2);
+    float* w = dev_rand(25 * ci * co, 0.05f, 3); float* b = dev_rand(256, 0.1f, 4);
+    float *o1, *o2; const size_t nout = tr ? nbig : nsm;
+    hipMalloc(&o1, nout * 4); hipMalloc(&o2, nout * 4);
+    void* planes; hipMalloc(&planes, split_planes_bytes(g));
+    launch_split_weights(w, planes, g, 0);
+    const float* in = tr ? small : big;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms[2];
+    for (int which = 0; which < 2; ++which) {
+      auto run = [&]() { if (which) launch_conv_taps_split(tr, in, planes, b, o2, g, 0); else launch_conv_taps_mfma(tr, in, w, b, o1, g, 0); };
+      for (int k = 0; k < 3; ++k) run();
+      hipDeviceSynchronize();
+      hipEventRecord(e0);
+      for (int k = 0; k < 20; ++k) run();
+      hipEventRecord(e1); hipDeviceSynchronize();
+      hipEventElapsedTime(&ms[which], e0, e1);
+    }
+    std::vector<float> h1(nout), h2(nout);
+    hipMemcpy(h1.data(), o1, nout * 4, hipMemcpyDeviceToHost); hipMemcpy(h2.data(), o2, nout * 4, hipMemcpyDeviceToHost);
+    double num = 0, den = 0, mx = 0;
+    for (size_t i = 0; i < nout; ++i) { const double d = (double)h1[i] - h2[i]; num += d * d; den += (double)h1[i] * h1[i]; if (std::fabs(d) > mx) mx = std::fabs(d); }
+    const double gf = 2.0 * nb * 256 * co * 25 * ci / 1e9;
+    printf("B %d ci %d co %d T %d : f32-MFMA %.1f us (%.0f TF)  split %.1f us (%.0f TF)   rel diff %.2e max %.2e\n", nb, ci, co, tr,
+           ms[0] * 50, gf / (ms[0] * 50e-6) / 1e3, ms[1] * 50, gf / (ms[1] * 50e-6) / 1e3, std::sqrt(num / den), mx);
+    fflush(stdout);
+    hipFree(big); hipFree(small); hipFree(w); hipFree(b); hipFree(o1); hipFree(o2); hipFree(planes);
+  }
+  return 0;
+}
