@@ -55,5 +55,25 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_tools(verbose=False):
+    """tools/bf16_unit.bin: every bf16 MFMA kernel alone against a double-precision reference (tests/test_bf16_kernels_gpu.py
+    runs it on the GPU box; built here because the box has no reason to have a compiler warmed up)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "bf16_unit.hip")
+    out = os.path.join(root, "tools", "bf16_unit.bin")
+    objs = [os.path.join(CSRC, os.path.splitext(s)[0] + ".o") for s in SOURCES if s != "runtime.cpp"]
+    deps = [src] + objs
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps if os.path.exists(d)):
+        return out
+    quiet = None if verbose else subprocess.DEVNULL
+    tobj = os.path.splitext(out)[0] + ".o"
+    for cmd in ([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-x", "hip", "-c", src, "-o", tobj],
+                [_hipcc(), "--offload-arch=gfx950", tobj] + objs + ["-o", out]):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, stdout=quiet, stderr=quiet)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

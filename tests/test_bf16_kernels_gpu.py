@@ -1,0 +1,38 @@
+"""Every bf16 MFMA kernel ALONE against a double-precision reference built from bf16-rounded operands
+(tools/bf16_unit.hip, compiled by __graft_entry__.build): 1x1 convolutions in all their fused forms, the backward pairs
+(data GEMM + weight gradient + bias gradient + squeeze-excite gate gradient), 5x5 stride-2 F-form / T-form and their
+weight gradients.  Products of bf16 numbers are exact in float32, so weight gradients must agree to float32 summation
+error; activations leave rounded to bf16 (2^-9 relative, 1.6e-3 norm-wise; one bit fewer for the conv2 pair's dt2)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from tests.common import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bf16_kernels_one_by_one():
+    from multiscale_variational_autoencoder_amd import _build
+    _build.build()
+    exe = _build.build_tools()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if "launched=" in ln]
+    assert len(lines) >= 20, r.stdout
+    assert "last hip error: no error" in r.stdout
+    for ln in lines:
+        assert "launched=1" in ln, ln
+        vals = {k: float(v) for k, v in re.findall(r"(\w+) rel=([0-9.eE+-]+)", ln)}
+        for k, v in vals.items():
+            if k in ("dW", "db"):
+                bound = 1e-6                     # exact products, float32 sums
+            elif k == "dot":
+                bound = 1e-5
+            elif ln.startswith("dual") and "mode=1" in ln:
+                bound = 8e-3                     # dt2: seven significant bits
+            else:
+                bound = 2.5e-3                   # bf16 output rounding
+            assert v <= bound, (ln, k, v, bound)

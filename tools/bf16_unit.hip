@@ -11,10 +11,12 @@
 using namespace mvae;
 namespace mvae {
 bool launch16_pw(bool transposed, const void* in, const float* w, const float* bias, const float* gate, const void* residual,
-                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s);
+                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s, bool out_f32 = false);
 bool launch16_dual(const void* X, const float* W, const void* aux, const float* gate, const void* residual, void* Y,
                    float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C, GradSlots sl, hipStream_t s, bool embed_mask = false);
-bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g, hipStream_t s);
+bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g,
+                   hipStream_t s, const float* w2 = nullptr, const float* bias2 = nullptr, void* out2 = nullptr,
+                   bool* chained = nullptr);
 bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s);
 }
 static uint16_t f2b(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
@@ -51,7 +53,8 @@ static void test_dual(int C, int mode) {
   for (int64_t m = 0; m < M; ++m) for (int ci = 0; ci < C; ++ci) {
     double a = 0, ae = 0; for (int co = 0; co < C; ++co) { a += (double)b2f(X[m * C + co]) * rb(W[ci * C + co]); ae += (double)b2f(X[m * C + co]) * W[ci * C + co]; }
     if (mode == 2) a += b2f(R[m * C + ci]);
-    Y[m * C + ci] = a;   // (mode 1: the kernel rounds one bit shorter and carries the mask of aux in the LSB: ~4e-3 rel) dot[(m / HW) * C + ci] += ae * b2f(A[m * C + ci]);
+    Y[m * C + ci] = a;   // (mode 1: the kernel rounds one bit shorter and carries the mask of aux in the LSB: ~4e-3 rel)
+    dot[(m / HW) * C + ci] += ae * b2f(A[m * C + ci]);     // dg = sum_hw (X . W^T with the float32 W) * aux
   }
   for (int64_t m = 0; m < M; ++m) for (int ci = 0; ci < C; ++ci) { const double av = (double)b2f(A[m * C + ci]) * (mode == 1 ? G[(m / HW) * C + ci] : 1.0);
     for (int co = 0; co < C; ++co) dW[ci * C + co] += av * b2f(X[m * C + co]); }
