@@ -100,6 +100,11 @@ int mvae_abi_version(void);
 /* 1 when the library was built with -DMVAE_DEBUG_BUILD (timing-diagnostic switches such as MVAE_DEBUG_ONLY_SCALE are
  * compiled in: results may then be garbage on request); 0 for the release build, which contains none of them. */
 int mvae_debug_build(void);
+/* Deterministic-reduction mode: MVAE_DETERMINISTIC=1 in the environment of mvae_create.  Every float reduction of the step
+ * then has a fixed order (one gradient / statistic slot per block folded in order, no split-K, single-pass gate gradients):
+ * repeated runs are bit-identical.  Float32 activations; needs 1024 gradient-arena copies of workspace.  1 = this handle
+ * runs in that mode. */
+int mvae_deterministic(const mvae_handle* h);
 /* The float32 5x5 stride-2 convolutions run as split-bf16 products on the bf16 matrix cores (csrc/kernels_split.hip:
  * float32 accuracy, 2.7x the float32-MFMA rate).  0 = switched off (MVAE_SPLIT_CONV=0), 1 = in use, 2 = disabled for this
  * process by the hardware self-test the first mvae_bind runs (a board on which a kernel running beside them returned

@@ -47,6 +47,7 @@ _H = C.c_void_p
 SYMBOLS = {
     "mvae_abi_version": (C.c_int, []),
     "mvae_debug_build": (C.c_int, []),
+    "mvae_deterministic": (C.c_int, [_H]),
     "mvae_split_conv_status": (C.c_int, []),
     "mvae_split_conv_erratum": (C.c_int, []),
     "mvae_create": (C.c_int, [C.POINTER(MvaeConfig), C.POINTER(_H)]),

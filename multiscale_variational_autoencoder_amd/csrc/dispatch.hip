@@ -11,6 +11,10 @@ Profiler& profiler() {
   return p;
 }
 
+static bool g_det_mode = false;
+bool det_mode() { return g_det_mode; }
+void set_det_mode(bool on) { g_det_mode = on; }
+
 static inline double f4(double n) { return 4.0 * n; }
 // tag with the row count (log2 bucket) so the profile separates the big launches from the launch-bound ones
 static const char* tagm(const char* base, double rows) {

@@ -22,6 +22,16 @@ struct PreOp {               // transform applied to the BIG-side operand when i
   const float* shift;        // [CI]
 };
 
+// ---- deterministic-reduction mode (MVAE_DETERMINISTIC=1, read by mvae_create) ----
+// Float atomics make a sum depend on the order in which blocks retire.  In this mode no accumulator cell receives more than
+// one atomic add: every kernel that reduces into gradient / statistic slots gets ONE SLOT PER BLOCK (kDetSlots copies, folded in
+// fixed order by k_slot_sum / the finalize kernels), split-K kernels run unsplit, the squeeze-excite gate gradient and the
+// global average pool are recomputed by single-pass kernels, and the 5x5 weight gradients take the slotted kernel.  Two runs
+// of the same step are then bit-identical (tests/test_deterministic_gpu.py).  Float32 activations only.
+constexpr int kDetSlots = 1024;
+bool det_mode();
+void set_det_mode(bool on);
+
 // ---- RNG (Philox4x32-10) ----
 // the seed is read from DEVICE memory so that a captured hipGraph stays valid from step to step
 void launch_set_u64(uint64_t* dst, uint64_t v, hipStream_t s);

@@ -372,7 +372,7 @@ static void run_skinny(bool nt, const T* A, const float* W1, const float* W2, co
                        float* o1, float* o2, int B, int K, int N1, int N2, hipStream_t s) {
   launch_zero(o1, (int64_t)B * N1, s);
   if (N2) launch_zero(o2, (int64_t)B * N2, s);
-  if (K % 256 == 0 && N1 >= 1) {
+  if (K % 256 == 0 && N1 >= 1 && !det_mode()) {
     const int ngroups = K / 256;
     dim3 grid((unsigned)(((B + 31) / 32) * ngroups));
     if (nt) hipLaunchKernelGGL((k_skinny_mfma256<true, T>), grid, dim3(256), 0, s, A, W1, W2, b1, b2, o1, o2, B, K, N1, N2, ngroups);
@@ -381,6 +381,7 @@ static void run_skinny(bool nt, const T* A, const float* W1, const float* W2, co
   }
   int KC = 256;
   while (KC > 8 && (int64_t)((B + 31) / 32) * ((K + KC - 1) / KC) < 512 && KC > 32) KC /= 2;   // >= ~512 waves
+  if (det_mode()) KC = (K + 7) / 8 * 8;              // deterministic mode: no split-K, every output gets one add onto zero
   const int nchunks = (K + KC - 1) / KC;
   const int64_t waves = (int64_t)((B + 31) / 32) * nchunks;
   dim3 grid((unsigned)((waves + 3) / 4));

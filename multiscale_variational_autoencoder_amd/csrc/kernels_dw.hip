@@ -529,7 +529,8 @@ static bool run_dw_fwd_gap(const T* in, const float* w, const float* b, T* out, 
   static const int fwd_items = [] { const char* e = getenv("MVAE_DW_FWD_ITEMS"); return e ? atoi(e) : 0; }();
   const int64_t target = fwd_items > 0 ? fwd_items : (sizeof(T) == 2 ? 1024 : 512);
   int nseg = 1;
-  while ((int64_t)B * g.strips * nseg < target && (H / (nseg * 2)) % 4 == 0 && H / (nseg * 2) >= 8) nseg *= 2;
+  while (!det_mode() && (int64_t)B * g.strips * nseg < target && (H / (nseg * 2)) % 4 == 0 && H / (nseg * 2) >= 8) nseg *= 2;
+  if (det_mode() && g.strips > 1) return false;          // several blocks per image would add their GAP shares atomically
   if ((int64_t)B * nseg > 65535) return false;
   if (g.strips * nseg > 1) launch_zero(gap, (int64_t)B * C, s);
   hipLaunchKernelGGL((k_dw_fwd_ring<true, T>), dim3(g.strips, B * nseg), dim3(256), lds, s, V4<T>(in), (const f32x4*)w,
@@ -550,6 +551,7 @@ static bool run_dw_bwd_fused(const T* dt2, const T* t1, const T* t0, const float
   if (dw_uses_img(true, mask_in_lsb, B, H, W, C)) {
     const int ipb = 256 / (H * (C / 4));
     const dim3 grid((unsigned)(B / ipb));
+    if (det_mode() && (int)grid.x > sl.count()) return false;   // one gradient slot per block
     const size_t bytes = (size_t)256 * W * sizeof(f32x4);
     const float inv = 1.0f / (float)(H * W);
 #define MVAE_DWB(W_)                                                                                                  \

@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256) k_head_bwd_reduce(const V4<T> x, const fl
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, float* __restrict__ S,
                                                          float* __restrict__ dW, float* __restrict__ db, int64_t M,
-                                                         int dc4, int64_t ppb, int nslots, int64_t slot_stride) {
+                                                         int dc4, int64_t ppb, int nslots, int64_t slot_stride, int nhead) {
   constexpr int NQ = 8 + 5 * C;                       // s1[4] s2[4] gw[4][C] gb[C]
   __shared__ float red[4][NQ][64];
   const int c4 = threadIdx.x % dc4, pl = threadIdx.x / dc4, npl = 256 / dc4;
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256) k_head_bwd_reduce(const V4<T> x, const fl
 #pragma unroll
   for (int k = 0; k < NQ; ++k) red[wave][k][lane] = q[k];
   __syncthreads();
-  float* Ss = S + (int64_t)(blockIdx.x % kHeadSlots) * 2 * dc4 * 4;
+  float* Ss = S + (int64_t)(blockIdx.x % nhead) * 2 * dc4 * 4;
   const int64_t gslot = (int64_t)(blockIdx.x % nslots) * slot_stride;
   float* dWs = dW + gslot;
   float* dbs = db + gslot;
@@ -501,18 +501,18 @@ bool launch_head_fwd(const float* x, const float* scale, const float* shift, con
                        bias, y, M, dc4, C);
   return true;
 }
-int head_slots() { return kHeadSlots; }
+int head_slots() { return det_mode() ? kDetSlots : kHeadSlots; }
 template <int C, typename T, typename TD>
 static void run_head_bwd(const T* x, const float* dy, const float* W, const float* gamma, const float* scale,
                          const float* shift, const float* mean, const float* invstd, float* S, float* dW, float* db,
                          float* dgamma, float* dbeta, TD* dout, int64_t M, int dc, GradSlots sl, hipStream_t s) {
   const int dc4 = dc / 4, npl = 256 / dc4;
   int64_t ppb = 16 * npl;                                  // >= 16 pixels per thread
-  while ((M + ppb - 1) / ppb > 2048) ppb *= 2;
+  while ((M + ppb - 1) / ppb > (det_mode() ? kDetSlots : 2048)) ppb *= 2;
   hipLaunchKernelGGL((k_head_bwd_reduce<C, T>), dim3((unsigned)((M + ppb - 1) / ppb)), dim3(256), 0, s, V4<T>(x), dy, W,
-                     scale, shift, mean, invstd, S, sl.at(dW), sl.at(db), M, dc4, ppb, sl.count(), sl.stride);
+                     scale, shift, mean, invstd, S, sl.at(dW), sl.at(db), M, dc4, ppb, sl.count(), sl.stride, head_slots());
   hipLaunchKernelGGL((k_head_bwd_apply<C, T, TD>), dim3(cap_grid((M + 4 * npl - 1) / (4 * npl))), dim3(256), 0, s,
-                     V4<T>(x), dy, W, gamma, mean, invstd, S, V4<TD>(dout), dgamma, dbeta, M, dc4, kHeadSlots);
+                     V4<T>(x), dy, W, gamma, mean, invstd, S, V4<TD>(dout), dgamma, dbeta, M, dc4, head_slots());
 }
 template <typename T, typename TD>
 static bool run_head_bwd_c(const T* x, const float* dy, const float* W, const float* gamma, const float* scale,

@@ -771,7 +771,7 @@ template <int MODE>
 static void launch_spatial(const float* a, const float* b, float* out, int B, int64_t HW, int C, float scale,
                            hipStream_t s) {
   int cpb = C < 256 ? C : 256;
-  int64_t ppb = 4096;
+  int64_t ppb = det_mode() ? (HW > 4096 ? HW : 4096) : 4096;     // deterministic mode: one block per (image, channel group)
   int64_t chunks = (HW + ppb - 1) / ppb;
   if (chunks > 1) launch_zero(out, (int64_t)B * C, s);
   hipLaunchKernelGGL(k_spatial<MODE>, dim3((unsigned)chunks, (C + cpb - 1) / cpb, B), dim3(256), 0, s, a, b, out, HW,

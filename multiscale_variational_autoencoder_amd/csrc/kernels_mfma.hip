@@ -740,7 +740,7 @@ static void run_wgrad_rows(const float* big, const float* small, float* dW, floa
   rpb = (rpb + 63) / 64 * 64;
   if (rpb < 64) rpb = 64;
   chunks = (M + rpb - 1) / rpb;
-  if (taps != 1) sl = GradSlots();                     // only the small 1x1 gradients are slotted (runtime: slot_chunks)
+  if (taps != 1 && !det_mode()) sl = GradSlots();      // only the small 1x1 gradients are slotted (runtime: slot_chunks)
   hipLaunchKernelGGL((k_wgrad_rows<CI, CO>), dim3((unsigned)chunks, taps), dim3(256), 0, s, big, small, sl.at(dW),
                      sl.at(db), g, pre, M, rpb, sl.count(), sl.stride);
 }
@@ -750,7 +750,7 @@ bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, flo
   if (2 * g.OW < 64 / (g.CI / 4)) return false;        // the kernel's branch-free row stepping wraps at most twice
 #define MVAE_WG(A, B_)                                                          \
   if (g.CI == A && g.CO == B_) {                                                \
-    if (!(g.KW == 5 && !pre.scale && !pre.gate && run_wgrad_taprow<A, B_>(big, small, dW, db, g, s)))  \
+    if (!(g.KW == 5 && !pre.scale && !pre.gate && !det_mode() && run_wgrad_taprow<A, B_>(big, small, dW, db, g, s)))  \
       run_wgrad_rows<A, B_>(big, small, dW, db, g, pre, sl, s);                     \
     return true;                                                                \
   }

@@ -140,6 +140,8 @@ struct mvae_handle {
   bool merge_side = false;
   bool multi_stream = true, use_graphs = true, wgrad_streams = false;
   bool lsb_mask = true;                     // the depthwise backward takes the ReLU mask from the LSB of dt2 (MVAE_LSB_MASK=0: reads t1)
+  bool det = false;                         // MVAE_DETERMINISTIC=1 at mvae_create: one slot per block, no split sums (kernels.h)
+  int nslots = kGradSlots, stat_slots = kStatSlots;
   hipStream_t side[MVAE_MAX_LEVELS] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MVAE_MAX_LEVELS] = {};
   std::map<std::string, hipGraphExec_t> graphs;
@@ -425,10 +427,10 @@ int build_plan(mvae_handle* h) {
     sc.out_w = b.param(D + ".out.w", {1, 1, ch, C}, MVAE_REG_L2);   sc.out_b = b.param(D + ".out.b", {C}, 0);
     float** small[] = {&sc.bn_mean, &sc.bn_invstd, &sc.bn_scale, &sc.bn_shift, &sc.bn_sum_d, &sc.bn_sum_dx};
     for (float** p : small) *p = as_ptr(b.ws_alloc(ch));
-    {   // column-statistic slot copies: [kStatSlots][ch] sums directly followed by [kStatSlots][ch] squared deviations
-      int64_t o = b.ws_alloc((int64_t)2 * kStatSlots * ch);
+    {   // column-statistic slot copies: [stat_slots][ch] sums directly followed by [stat_slots][ch] squared deviations
+      int64_t o = b.ws_alloc((int64_t)2 * h->stat_slots * ch);
       sc.bn_sum = as_ptr(o);
-      sc.bn_sqdev = as_ptr(o + (int64_t)kStatSlots * ch);
+      sc.bn_sqdev = as_ptr(o + (int64_t)h->stat_slots * ch);
     }
     sc.head_S = as_ptr(b.ws_alloc((int64_t)head_slots() * 2 * ch));
     sc.y = as_ptr(b.act(D + ".y", hwC));
@@ -470,8 +472,10 @@ int build_plan(mvae_handle* h) {
       h->chunks.push_back(cd);
     }
   }
+  // deterministic mode: every gradient a slotted kernel produces goes through the slots (the 5x5 weights too); the big
+  // Dense weights are written by kernels that own their outputs
   for (const ChunkDesc& cd : h->chunks)
-    if (h->params[cd.tensor].elems <= kSlotMaxElems) h->slot_chunks.push_back(cd);
+    if (h->params[cd.tensor].elems <= kSlotMaxElems || (h->det && cd.offset >= h->reduce_split)) h->slot_chunks.push_back(cd);
   for (const StateInfo& s : h->states) {
     StateDesc sd;
     sd.offset = s.offset; sd.len = (int32_t)s.elems; sd.momentum = s.momentum;
@@ -485,7 +489,7 @@ int build_plan(mvae_handle* h) {
   h->off_norms = b.ws_alloc(2 * (int64_t)h->chunks.size());      // one partial ||g||^2 per chunk, then one total per tensor
   h->off_seed = b.ws_alloc(kAlign);
   h->off_hp = b.ws_alloc(kAlign);
-  h->off_slots = b.ws_alloc((int64_t)kGradSlots * h->P);
+  h->off_slots = b.ws_alloc((int64_t)h->nslots * h->P);
   h->ws_floats = b.wcur;
   return MVAE_OK;
 }
@@ -523,7 +527,7 @@ void rebase_all(mvae_handle* h) {
   h->d_norms = base + h->off_norms;
   h->gslots.base = base + h->off_slots;
   h->gslots.stride = h->P;
-  h->gslots.n = kGradSlots;
+  h->gslots.n = h->nslots;
 }
 
 // ---- scratch pool (per scale, static order => stable pointers under graph capture) ----------
@@ -732,6 +736,12 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
     dual2 = launch_gemm_dual_mfma(dout, P + m.w2, m.t1, m.g, nullptr, bufB, G + m.w2, G + m.b2, dg, (int64_t)B * HW, HW,
                                   c, h->gslots, m.dg_slots, dg_stride, s);
   }
+  if (dual2 && h->det) {
+    // deterministic mode: the gate gradient again as one pass per (image, channel) -- the dual kernel's own dot product is
+    // added by several waves per cell.  (dt2 carries the ReLU mask in its LSB: at most one ulp per term.)
+    launch_zero(dg, (int64_t)m.dg_slots * dg_stride, s);
+    launch_spatial_dot(bufB, m.t1, dg, B, HW, c, s);
+  }
   if (!dual2) {
     {
       hipStream_t w = wgrad_begin(h, sc, s);                                           // dout is ready on the chain
@@ -836,19 +846,19 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
   // batch statistics (two-pass, multiscale_vae.py:420-421): column sums, then squared deviations, each into
   // kStatSlots slot copies that the finalize kernel folds
   if (training) {
-    launch_zero(sc.bn_sum, (int64_t)2 * kStatSlots * sc.dc, s);               // bn_sum and bn_sqdev are adjacent
+    launch_zero(sc.bn_sum, (int64_t)2 * h->stat_slots * sc.dc, s);            // bn_sum and bn_sqdev are adjacent
     // (x = the last block's output: float32 storage in either mode, see MN::out_f32)
-    const bool cs0 = launch_colstat_opt(0, x, nullptr, 0, 0.f, sc.bn_sum, kStatSlots, sc.dc, M, sc.dc, s, false);
+    const bool cs0 = launch_colstat_opt(0, x, nullptr, 0, 0.f, sc.bn_sum, h->stat_slots, sc.dc, M, sc.dc, s, false);
     if (sc.bf) need16(h, cs0);
     if (!cs0) launch_colsum(x, sc.bn_sum, M, sc.dc, s);
-    if (!launch_colstat_opt(1, x, sc.bn_sum, kStatSlots, 1.0f / (float)M, sc.bn_sqdev, kStatSlots, sc.dc, M, sc.dc, s, false)) {
+    if (!launch_colstat_opt(1, x, sc.bn_sum, h->stat_slots, 1.0f / (float)M, sc.bn_sqdev, h->stat_slots, sc.dc, M, sc.dc, s, false)) {
       launch_bn2d_mean(sc.bn_sum, nullptr, sc.bn_mean, M, sc.dc, 1, s);
       launch_colsqdev(x, sc.bn_mean, sc.bn_sqdev, M, sc.dc, s);
     }
   }
   launch_bn2d_finalize(sc.bn_sum, sc.bn_sqdev, P + sc.bn_g, P + sc.bn_b, h->ds + sc.st_bn_mean, h->ds + sc.st_bn_var,
                        sc.bn_mean, sc.bn_invstd, sc.bn_scale, sc.bn_shift, stats + sc.st_bn_mean,
-                       stats + sc.st_bn_var, M, sc.dc, kDecBnEps, training ? 1 : 0, kStatSlots, s);
+                       stats + sc.st_bn_var, M, sc.dc, kDecBnEps, training ? 1 : 0, h->stat_slots, s);
   ProfScope ps("head_fwd", 4.0 * M * (sc.dc + sc.C), 2.0 * M * sc.dc * sc.C, s);
   const bool hf = launch_head_fwd(x, sc.bn_scale, sc.bn_shift, P + sc.out_w, P + sc.out_b, sc.y, M, sc.dc, sc.C, s, false);
   if (sc.bf) need16(h, hf);
@@ -961,6 +971,7 @@ extern "C" {
 
 int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
 
+int mvae_deterministic(const mvae_handle* h) { return h ? (h->det ? 1 : 0) : MVAE_E_INVALID; }
 int mvae_split_conv_status(void) { return split_conv_status(); }
 int mvae_split_conv_erratum(void) { return split_conv_erratum_count(); }
 
@@ -1004,7 +1015,17 @@ int mvae_create(const mvae_config* cfg, mvae_handle** out) {
     return fail(nullptr, MVAE_E_INVALID, "act_dtype must be MVAE_ACT_F32 or MVAE_ACT_BF16");
   mvae_handle* h = new mvae_handle();
   h->cfg = *cfg;
+  if (const char* v = getenv("MVAE_DETERMINISTIC")) h->det = atoi(v) != 0;
+  if (h->det) {
+    if (cfg->act_dtype != MVAE_ACT_F32) { delete h; return fail(nullptr, MVAE_E_INVALID, "MVAE_DETERMINISTIC=1 supports float32 activations only"); }
+    h->nslots = kDetSlots; h->stat_slots = kDetSlots;
+  }
+  set_det_mode(h->det);
   int rc = build_plan(h);
+  if (rc == MVAE_OK && h->det && (int64_t)h->nslots * h->P * 4 > (24LL << 30)) {
+    delete h;
+    return fail(nullptr, MVAE_E_NOMEM, "MVAE_DETERMINISTIC=1: %d gradient-slot copies of this model exceed 24 GB", kDetSlots);
+  }
   if (rc != MVAE_OK) { delete h; return rc; }
   *out = h;
   return MVAE_OK;
@@ -1070,7 +1091,7 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   h->dp = params; h->dr = reduce_arena; h->da = accum; h->ds = state; h->ws = static_cast<float*>(workspace);
   rebase_all(h);
   h->gslots.gbase = h->dr;
-  if (const char* v = getenv("MVAE_GRAD_SLOTS")) h->gslots.n = atoi(v) > 0 && atoi(v) <= kGradSlots ? atoi(v) : 0;
+  if (const char* v = getenv("MVAE_GRAD_SLOTS")) { if (!h->det) h->gslots.n = atoi(v) > 0 && atoi(v) <= kGradSlots ? atoi(v) : 0; }
   e = hipMemcpy(h->d_chunks, h->chunks.data(), h->chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
   if (e == hipSuccess && !h->slot_chunks.empty())
     e = hipMemcpy(h->d_slot_chunks, h->slot_chunks.data(), h->slot_chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
@@ -1142,6 +1163,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
   const bool training = io->training != 0;
   const float* P = h->dp;
   h->kernel_gap = false;                   // per call: an earlier failed call must not poison the handle
+  set_det_mode(h->det);
   const int64_t hwC = (int64_t)c.input_h * c.input_w * C;
   float* metrics = h->dr + h->P + h->S;
   const mvae_step_io io_c = *io;
@@ -1262,6 +1284,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
   const float* P = h->dp;
   float* G = h->dr;
   h->kernel_gap = false;
+  set_det_mode(h->det);
   // loss factors go through the device hyper-parameter block: the captured graph does not depend on their values
   launch_set_f3(h->d_hp + HP_RF_OVER_B, r_factor / (float)B, kl_factor / (float)B, 0.f, 2, s0);
   // phase bit 1: loss, decoder halves, Dense gradients (everything that fills the leading arena region);
@@ -1526,6 +1549,7 @@ int mvae_decode(mvae_handle* h, const float* z, int32_t batch, float* recon, voi
   if (batch <= 0 || batch > c.max_batch) return fail(h, MVAE_E_INVALID, "batch %d outside [1, %d]", batch, c.max_batch);
   hipStream_t s = static_cast<hipStream_t>(stream);
   h->kernel_gap = false;
+  set_det_mode(h->det);
   for (Scale& sc : h->scales) {
     launch_copy_cols(z, (int)h->Z, sc.z_off, sc.zs, sc.z, 0, batch, sc.z, s);
     decoder_forward(h, sc, batch, false, s);
