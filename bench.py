@@ -422,6 +422,11 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "collective": coll_desc},
         "finite": finite, "debug_env": debug_env,
+        # float32 5x5 convolutions as split-bf16 products (csrc/kernels_split.hip): status 1 = in use, 0 = switched off, 2 =
+        # disabled by the bind-time hardware self-test; erratum = wrong values the self-test's v_pk_fma_f32 check kernel
+        # returned on this board (the build emits no packed-float32 instructions because of it)
+        "split_conv": {"status": int(_abi.load_library().mvae_split_conv_status()),
+                       "packed_f32_erratum_wrong_values": int(_abi.load_library().mvae_split_conv_erratum())},
         "timing": {"ms_per_step_median_events": med, "ms_per_step_min_events": float(per_step.min()),
                    "ms_per_step_p90_events": float(np.percentile(per_step, 90)),
                    "images_per_sec_median_events": B * world / (med * 1e-3),

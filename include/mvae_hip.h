@@ -195,6 +195,30 @@ int mvae_laplacian_merge_mix(int32_t device, const float* const* in, int32_t bat
                              const float* const* w1, float min_value, float max_value, float* out, float* work,
                              void* stream);
 
+/* ---- stand-alone blocks of the reference's block library: forward and backward, stateless; all
+ *      tensors NHWC float32 device memory, weights in the Keras layouts, gradients are ADDED to dw / db (zero them first).
+ *      mobilenetV2_block (layer_blocks.py:468-550; use_batchnorm=False, dropout 0 -- the reference's defaults):
+ *        t0 = x.W0 + b0 [B,H,W,F];  t1 = relu(dw3x3(t0, Wd) + bd);  u = relu(t1.W2 + b2) [B,H,W,C];  y = u + x
+ *        W0 [1,1,C,F], Wd [3,3,F,1], W2 [1,1,F,C].  backward work: >= B*H*W*(C + 2F) floats.
+ *      resnet_block (layer_blocks.py:789-887; strides (1,1), use_batchnorm=False, dropout 0; relu != 0: activation "relu",
+ *      else "linear"):  x0 = act(conv(x, W0) + b0);  y = act(conv(x0, W1) + b1 + skip),  skip = x if C == F else x.Ws + bs
+ *        W0 [kh,kw,C,F], W1 [kh,kw,F,F], Ws [1,1,C,F] (NULL when C == F; `skip` buffer [B,H,W,F] likewise).
+ *        backward work: >= B*H*W*(2F + C) floats. ---- */
+int mvae_mnv2_forward(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t F, const float* w0,
+                      const float* b0, const float* wd, const float* bd, const float* w2, const float* b2, float* t0,
+                      float* t1, float* u, float* y, void* stream);
+int mvae_mnv2_backward(int32_t device, const float* x, const float* t0, const float* t1, const float* u, const float* dy,
+                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t F, const float* w0, const float* wd,
+                       const float* w2, float* dx, float* dw0, float* db0, float* dwd, float* dbd, float* dw2, float* db2,
+                       float* work, void* stream);
+int mvae_resnet_forward(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t F, int32_t kh,
+                        int32_t kw, int32_t relu, const float* w0, const float* b0, const float* w1, const float* b1,
+                        const float* ws, const float* bs, float* x0, float* skip, float* y, void* stream);
+int mvae_resnet_backward(int32_t device, const float* x, const float* x0, const float* y, const float* dy, int32_t B, int32_t H,
+                         int32_t W, int32_t C, int32_t F, int32_t kh, int32_t kw, int32_t relu, const float* w0,
+                         const float* w1, const float* ws, float* dx, float* dw0, float* db0, float* dw1, float* db1,
+                         float* dws, float* dbs, float* work, void* stream);
+
 /* ---- diagnostics (process-global): per-launch HIP-event timing on the launch stream, used by bench.py for
  *      the per-kernel roofline line.  report writes a JSON object {tag: {count, ms, bytes, flops}} (algorithmic
  *      bytes / flops summed over the launches), returns its length, and clears the records; it synchronises. ---- */

@@ -83,6 +83,10 @@ SYMBOLS = {
     "mvae_laplacian_merge_mix": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_void_p), C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mvae_mnv2_forward": (C.c_int, [C.c_int32, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] * 10 + [C.c_void_p]),
+    "mvae_mnv2_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p] * 11 + [C.c_void_p]),
+    "mvae_resnet_forward": (C.c_int, [C.c_int32, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p] * 9 + [C.c_void_p]),
+    "mvae_resnet_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 8 + [C.c_void_p] * 11 + [C.c_void_p]),
     "mvae_profile_enable": (C.c_int, [C.c_int32]),
     "mvae_profile_report": (C.c_int64, [C.c_char_p, C.c_int64]),
     "mvae_tensor_lookup": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),

@@ -278,6 +278,12 @@ bool launch_dense_wgrad_dec(const float* z, const float* dy, float* dW, float* d
                             bool bf = false);
 void launch_add_vec2(float* o0, const float* a0, float* o1, const float* a1, int n, hipStream_t s);
 
+// ---- glue of the stand-alone block library (kernels_blocks.hip) ----
+void launch_relu_bwd(const float* dy, const float* y, float* out, int64_t n, hipStream_t s);       // out = dy * (y > 0)
+void launch_relu_add(float* y, const float* r, bool relu, int64_t n, hipStream_t s);             // y = [relu](y) (+ r)
+void launch_add2(const float* a, const float* b, float* out, int64_t n, hipStream_t s);
+void launch_dw_bwd_plain(const float* dy, const float* w, float* dx, int B, int H, int W, int C, hipStream_t s);
+
 // ---- float32 k x k convolutions as split-bf16 products on the bf16 matrix cores (kernels_split.hip) ----
 // x = x1 + x2 + x3 (three exact bf16 pieces), six bf16 MFMAs per product: float32 accuracy at 2.7x the f32-MFMA rate.
 bool split_conv_covers(const ConvGeom& g);                     // 5x5-like layers between 32 and 64 channels

@@ -1000,7 +1000,10 @@ __global__ void __launch_bounds__(256, 2) k16_wgrad(const bf16_t* __restrict__ b
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
-static int cus16() { return 256; }
+static int cus16() {
+  static const int v = [] { const char* e = getenv("MVAE_BIG_CUS16"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  return v;
+}
 
 // 1x1 convolution forward / transposed.  false = shape not covered.
 bool launch16_pw(bool transposed, const void* in, const float* w, const float* bias, const float* gate, const void* residual,

@@ -117,15 +117,16 @@ __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__
 // in straight-line code hipcc counts the outstanding loads exactly (s_waitcnt vmcnt(N > 0)), so a tap's data is waited
 // for with the PF - 1 younger fetches still in flight.
 // =================================================================================================
-template <int KC, int NC, bool TFORM, int NKH, int NKW, int PF>
+template <int KC, int NC, bool TFORM, int NKH, int NKW, int PF, int NW>
 struct ConvTapsS {
   static constexpr int NT = NC / 32, KK = KC / 16, Q = KC / 8;       // Q = 16-byte float32 chunks a lane fetches per tap
   static constexpr int CPP = KC / 4, PPI = 64 / CPP;                 // lanes per pixel, pixels per load instruction
   static constexpr int PLANE_W = NC * KC * 2, TAPB = 3 * PLANE_W;    // bytes
   static constexpr int PLANE_A = 32 * KC * 2;
-  static constexpr int WLD = TAPB / (256 * 16);                      // 16-byte pieces of a weight slice per thread
+  static constexpr int NTHR = 64 * NW;                               // NW waves share one staged weight slice
+  static constexpr int WLD = (TAPB + NTHR * 16 - 1) / (NTHR * 16);   // 16-byte pieces of a weight slice per thread
   static constexpr int NTAPS = NKH * NKW;
-  static_assert(TAPB % (256 * 16) == 0, "weight slice is a whole number of 16-byte pieces per thread");
+  static constexpr bool WRAG = TAPB % (NTHR * 16) != 0;              // the last piece exists for part of the threads only
 
   // kernel column of tap-list position tw: F-form with stride 2 walks a kernel row as kw = 0, 2, 4, 1, 3 (consecutive taps
   // touch the same cache lines, see k_conv_taps)
@@ -185,7 +186,10 @@ struct ConvTapsS {
       const int kh = kh0 + th * khs, kw = kw0 + col_of(tw) * kws;
       const u32x4* wt = reinterpret_cast<const u32x4*>(Wp + (size_t)(kh * g.KW + kw) * TAPB);
 #pragma unroll
-      for (int u = 0; u < WLD; ++u) wreg[slot][u] = wt[threadIdx.x + u * 256];
+      for (int u = 0; u < WLD; ++u) {
+        const int idx = (int)threadIdx.x + u * NTHR;
+        wreg[slot][u] = wt[(WRAG && idx * 16 >= TAPB) ? (int)threadIdx.x : idx];        // (clamped: loaded, not stored)
+      }
       const unsigned delta = (unsigned)((dyv[th] * SWw + dxv[tw]) * KC * 4);
       const unsigned sel = (1u << th) | (0x100u << tw);
 #pragma unroll
@@ -200,7 +204,10 @@ struct ConvTapsS {
     auto split_slot = [&](int slot, int j) { split4(areg[slot][j], sp[j][0], sp[j][1], sp[j][2]); };
     auto store = [&](int slot, int buf) {                   // weights as they are; pixels: the three planes of every slot
 #pragma unroll
-      for (int u = 0; u < WLD; ++u) reinterpret_cast<u32x4*>(sW[buf])[threadIdx.x + u * 256] = wreg[slot][u];
+      for (int u = 0; u < WLD; ++u) {
+        const int idx = (int)threadIdx.x + u * NTHR;
+        if (!WRAG || idx * 16 < TAPB) reinterpret_cast<u32x4*>(sW[buf])[idx] = wreg[slot][u];
+      }
 #pragma unroll
       for (int j = 0; j < Q; ++j) {
         const int pl = lp + PPI * j;
@@ -291,13 +298,13 @@ struct ConvTapsS {
 
 // F-form: KH x KW = 5 x 5 (any stride / padding).  T-form: stride 2 x 2, 5 x 5: a sub-pixel phase (blockIdx.y) has 3 or 2 tap
 // rows and columns.  Other geometries take the float32 kernels (launcher).
-template <int KC, int NC, bool TFORM, int PF>
-__global__ void __launch_bounds__(256, (KC == 32 && PF == 2) ? 3 : 2)
+template <int KC, int NC, bool TFORM, int PF, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : ((KC == 32 && PF == 2) ? 3 : 2))
 k_conv_taps_s(const float* __restrict__ in, const char* __restrict__ Wp, const float* __restrict__ bias,
               float* __restrict__ out, ConvGeom g, unsigned in_bytes, unsigned out_bytes) {
   constexpr int TAPB = 3 * NC * KC * 2, PLANE_A = 32 * KC * 2;
   __shared__ __attribute__((aligned(16))) char sW[2][TAPB];
-  __shared__ __attribute__((aligned(16))) char sA[4][3 * PLANE_A];
+  __shared__ __attribute__((aligned(16))) char sA[NW][3 * PLANE_A];
   const int wave = threadIdx.x >> 6;
   int py = 0, px = 0, CH = g.OH, CW = g.OW;
   if (TFORM) {
@@ -305,13 +312,13 @@ k_conv_taps_s(const float* __restrict__ in, const char* __restrict__ Wp, const f
     CH = (g.IH - py + g.SH - 1) / g.SH; CW = (g.IW - px + g.SW - 1) / g.SW;
   }
   const unsigned Mc = (unsigned)(g.B * CH * CW);
-  const unsigned p0 = blockIdx.x * 128u;
+  const unsigned p0 = blockIdx.x * (32u * NW);
   if (p0 >= Mc) return;                         // block-uniform
   if constexpr (!TFORM) {
-    ConvTapsS<KC, NC, false, 5, 5, PF>::run(in, Wp, bias, out, g, in_bytes, out_bytes, sW, sA[wave], 0, 0, 0, 0, CH, CW, p0, Mc);
+    ConvTapsS<KC, NC, false, 5, 5, PF, NW>::run(in, Wp, bias, out, g, in_bytes, out_bytes, sW, sA[wave], 0, 0, 0, 0, CH, CW, p0, Mc);
   } else {
     const int kh0 = (py + g.PT) % g.SH, kw0 = (px + g.PL) % g.SW;     // 0 -> taps 0, 2, 4;  1 -> taps 1, 3
-#define MVAE_PH(A, B_) ConvTapsS<KC, NC, true, A, B_, PF>::run(in, Wp, bias, out, g, in_bytes, out_bytes, sW, sA[wave], py, px, kh0, kw0, CH, CW, p0, Mc)
+#define MVAE_PH(A, B_) ConvTapsS<KC, NC, true, A, B_, PF, NW>::run(in, Wp, bias, out, g, in_bytes, out_bytes, sW, sA[wave], py, px, kh0, kw0, CH, CW, p0, Mc)
     if (kh0 == 0) { if (kw0 == 0) MVAE_PH(3, 3); else MVAE_PH(3, 2); }
     else { if (kw0 == 0) MVAE_PH(2, 3); else MVAE_PH(2, 2); }
 #undef MVAE_PH
@@ -571,15 +578,15 @@ bool launch_conv_taps_split(bool transposed, const float* in, const void* planes
   else Mc = (int64_t)g.B * g.OH * g.OW;
   const unsigned in_bytes = (unsigned)((int64_t)g.B * (transposed ? g.OH * g.OW : g.IH * g.IW) * KC * 4);
   const unsigned out_bytes = (unsigned)((int64_t)g.B * (transposed ? g.IH * g.IW * g.CI : g.OH * g.OW * g.CO) * 4);
+  // 4 waves per block (128 output pixels share a staged weight slice); 8-wave blocks measured 5-10 % slower on all four forms
   const dim3 grid((unsigned)((Mc + 127) / 128), classes);
   const int taps = g.KH * g.KW;
   const char* pF = static_cast<const char*>(planes);
   const char* pT = pF + (int64_t)taps * 3 * g.CI * g.CO * 2;
   // PF taps of register prefetch: 3 where a tap's pixels are 16 registers (KC = 32), 2 where they are 32 (KC = 64)
-#define MVAE_CS(A, B_, TF, PF_, P) hipLaunchKernelGGL((k_conv_taps_s<A, B_, TF, PF_>), grid, dim3(256), 0, s, in, P, bias, out, g, in_bytes, out_bytes)
-  static const int pf32 = getenv("MVAE_SPLIT_PF") ? atoi(getenv("MVAE_SPLIT_PF")) : 3;
-  if (!transposed) { if (g.CI == 32) { if (pf32 == 2) MVAE_CS(32, 64, false, 2, pF); else MVAE_CS(32, 64, false, 3, pF); } else MVAE_CS(64, 32, false, 2, pF); }
-  else { if (g.CO == 32) { if (pf32 == 2) MVAE_CS(32, 64, true, 2, pT); else MVAE_CS(32, 64, true, 3, pT); } else MVAE_CS(64, 32, true, 2, pT); }
+#define MVAE_CS(A, B_, TF, PF_, P) hipLaunchKernelGGL((k_conv_taps_s<A, B_, TF, PF_, 4>), grid, dim3(256), 0, s, in, P, bias, out, g, in_bytes, out_bytes)
+  if (!transposed) { if (g.CI == 32) MVAE_CS(32, 64, false, 3, pF); else MVAE_CS(64, 32, false, 2, pF); }
+  else { if (g.CO == 32) MVAE_CS(32, 64, true, 3, pT); else MVAE_CS(64, 32, true, 2, pT); }
 #undef MVAE_CS
   return true;
 }

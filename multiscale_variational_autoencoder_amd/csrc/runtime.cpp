@@ -1655,6 +1655,102 @@ int mvae_laplacian_merge_mix(int32_t device, const float* const* in, int32_t bat
   return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
 }
 
+// ---- stand-alone blocks of the reference's block library, stateless ------------------------------
+static ConvGeom geom_same(int B, int H, int W, int ci, int co, int kh, int kw) {
+  ConvGeom g{};
+  g.B = B; g.IH = g.OH = H; g.IW = g.OW = W; g.CI = ci; g.CO = co; g.KH = kh; g.KW = kw; g.SH = g.SW = 1;
+  g.PT = (kh - 1) / 2; g.PL = (kw - 1) / 2;                     // TF 'SAME' at stride 1: total k - 1, the smaller half first
+  return g;
+}
+
+int mvae_mnv2_forward(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t F, const float* w0,
+                      const float* b0, const float* wd, const float* bd, const float* w2, const float* b2, float* t0,
+                      float* t1, float* u, float* y, void* stream) {
+  if (!x || !w0 || !b0 || !wd || !bd || !w2 || !b2 || !t0 || !t1 || !u || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || F <= 0)
+    return MVAE_E_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  PreOp none{nullptr, nullptr, nullptr};
+  launch_conv_f(x, w0, b0, nullptr, t0, geom_same(B, H, W, C, F, 1, 1), none, ACT_NONE, s);      // conv0: 1x1, linear (:503-511)
+  launch_dw_fwd(t0, wd, bd, t1, B, H, W, F, s);                                                  // conv1: depthwise 3x3, relu (:513-521)
+  launch_conv_f(t1, w2, b2, nullptr, u, geom_same(B, H, W, F, C, 1, 1), none, ACT_RELU, s);      // conv2: 1x1, relu (:527-535)
+  launch_add2(u, x, y, (int64_t)B * H * W * C, s);                                               // Add (:542-545)
+  return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
+}
+
+int mvae_mnv2_backward(int32_t device, const float* x, const float* t0, const float* t1, const float* u, const float* dy,
+                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t F, const float* w0, const float* wd,
+                       const float* w2, float* dx, float* dw0, float* db0, float* dwd, float* dbd, float* dw2, float* db2,
+                       float* work, void* stream) {
+  if (!x || !t0 || !t1 || !u || !dy || !w0 || !wd || !w2 || !dx || !dw0 || !db0 || !dwd || !dbd || !dw2 || !db2 || !work ||
+      B <= 0 || H <= 0 || W <= 0 || C <= 0 || F <= 0)
+    return MVAE_E_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t M = (int64_t)B * H * W;
+  float *du = work, *d1 = work + M * C, *dt0 = d1 + M * F;
+  PreOp none{nullptr, nullptr, nullptr};
+  GradSlots direct;
+  const ConvGeom g0 = geom_same(B, H, W, C, F, 1, 1), g2 = geom_same(B, H, W, F, C, 1, 1);
+  launch_relu_bwd(dy, u, du, M * C, s);                                       // through conv2's relu
+  launch_conv_wgrad(t1, du, dw2, db2, g2, none, direct, s);                   // dW2 += t1^T du, db2 += sum du
+  launch_conv_t(du, w2, nullptr, nullptr, d1, g2, s);                         // dt1 = du . W2^T
+  launch_relu_bwd(d1, t1, d1, M * F, s);                                      // through the depthwise relu
+  launch_dw_wgrad(t0, d1, dwd, dbd, B, H, W, F, s);
+  launch_dw_bwd_plain(d1, wd, dt0, B, H, W, F, s);                            // conv0 is linear: no mask behind the depthwise
+  launch_conv_wgrad(x, dt0, dw0, db0, g0, none, direct, s);
+  launch_conv_t(dt0, w0, nullptr, dy, dx, g0, s);                             // dx = dt0 . W0^T + dy (the skip connection)
+  return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
+}
+
+int mvae_resnet_forward(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t F, int32_t kh,
+                        int32_t kw, int32_t relu, const float* w0, const float* b0, const float* w1, const float* b1,
+                        const float* ws, const float* bs, float* x0, float* skip, float* y, void* stream) {
+  if (!x || !w0 || !b0 || !w1 || !b1 || !x0 || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || F <= 0 || kh <= 0 || kw <= 0)
+    return MVAE_E_INVALID;
+  if (C != F && (!ws || !bs || !skip)) return MVAE_E_INVALID;              // a 1x1 skip convolution when the widths differ
+  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  PreOp none{nullptr, nullptr, nullptr};
+  launch_conv_f(x, w0, b0, nullptr, x0, geom_same(B, H, W, C, F, kh, kw), none, relu ? ACT_RELU : ACT_NONE, s);   // conv0 (:830-838)
+  const float* sk = x;                                                                                       // skip (:858-872)
+  if (C != F) { launch_conv_f(x, ws, bs, nullptr, skip, geom_same(B, H, W, C, F, 1, 1), none, ACT_NONE, s); sk = skip; }
+  launch_conv_f(x0, w1, b1, sk, y, geom_same(B, H, W, F, F, kh, kw), none, ACT_NONE, s);                     // conv1 + Add (:840-848, 874)
+  if (relu) launch_relu_add(y, nullptr, true, (int64_t)B * H * W * F, s);                                    // Activation (:877-879)
+  return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
+}
+
+int mvae_resnet_backward(int32_t device, const float* x, const float* x0, const float* y, const float* dy, int32_t B, int32_t H,
+                         int32_t W, int32_t C, int32_t F, int32_t kh, int32_t kw, int32_t relu, const float* w0,
+                         const float* w1, const float* ws, float* dx, float* dw0, float* db0, float* dw1, float* db1,
+                         float* dws, float* dbs, float* work, void* stream) {
+  if (!x || !x0 || !y || !dy || !w0 || !w1 || !dx || !dw0 || !db0 || !dw1 || !db1 || !work || B <= 0 || H <= 0 || W <= 0 ||
+      C <= 0 || F <= 0 || kh <= 0 || kw <= 0)
+    return MVAE_E_INVALID;
+  if (C != F && (!ws || !dws || !dbs)) return MVAE_E_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t M = (int64_t)B * H * W;
+  float *dpre = work, *d0 = work + M * F, *tmp = d0 + M * F;               // [M,F], [M,F], [M,C]
+  PreOp none{nullptr, nullptr, nullptr};
+  GradSlots direct;
+  const ConvGeom g0 = geom_same(B, H, W, C, F, kh, kw), g1 = geom_same(B, H, W, F, F, kh, kw), gs = geom_same(B, H, W, C, F, 1, 1);
+  if (relu) launch_relu_bwd(dy, y, dpre, M * F, s);
+  else (void)hipMemcpyAsync(dpre, dy, sizeof(float) * M * F, hipMemcpyDeviceToDevice, s);
+  launch_conv_wgrad(x0, dpre, dw1, db1, g1, none, direct, s);
+  launch_conv_t(dpre, w1, nullptr, nullptr, d0, g1, s);                    // gradient at conv0's output
+  if (relu) launch_relu_bwd(d0, x0, d0, M * F, s);
+  launch_conv_wgrad(x, d0, dw0, db0, g0, none, direct, s);
+  if (C == F) {
+    launch_conv_t(d0, w0, nullptr, dpre, dx, g0, s);                       // identity skip: dx = d0 * W0^T + dpre
+  } else {
+    launch_conv_wgrad(x, dpre, dws, dbs, gs, none, direct, s);
+    launch_conv_t(dpre, ws, nullptr, nullptr, tmp, gs, s);
+    launch_conv_t(d0, w0, nullptr, tmp, dx, g0, s);
+  }
+  return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
+}
+
 int mvae_profile_enable(int32_t on) {
   Profiler& p = profiler();
   p.on = on != 0;

@@ -210,3 +210,200 @@ def laplacian_transform_merge(input_dims, levels, name=None, min_value=0.0, max_
     if trainable:
         return LaplacianMergeMix(input_dims, levels, name, min_value, max_value, filters, activation, kernel_initializer)
     return LaplacianMerge(input_dims, levels, name, min_value, max_value)
+
+
+# ==============================================================================
+# mobilenetV2_block and resnet_block of the reference's block library as stand-alone HIP layers.
+# The reference's functions take a Keras tensor and return a Keras tensor; here the factory takes the input shape and
+# returns a layer object that owns its weights (glorot_normal kernels, zero biases, like the reference's defaults) and
+# offers forward / backward through the C ABI (mvae_mnv2_* / mvae_resnet_*).
+# ==============================================================================
+class _HipBlock(_HipModel):
+    def __init__(self, name, input_dims, filters, shapes, seed, device):
+        super().__init__(name, device)
+        self.input_dims = tuple(int(d) for d in input_dims)
+        self.filters = int(filters)
+        from .initializers import truncated_normal, _TRUNC_STD
+        rng = np.random.default_rng(seed)
+        self._weights = {}
+        for k, shp in shapes.items():
+            if k.endswith(".b"):
+                self._weights[k] = np.zeros(shp, np.float32)
+            else:
+                kh, kw, ci, co = shp
+                fan_in, fan_out = kh * kw * ci, kh * kw * co        # keras: receptive field x channels (depthwise: co = 1)
+                self._weights[k] = truncated_normal(rng, shp, np.sqrt(2.0 / (fan_in + fan_out)) / _TRUNC_STD)
+        self._saved = None
+
+    def get_weights(self):
+        return {k: v.copy() for k, v in self._weights.items()}
+
+    def set_weights(self, weights):
+        for k, v in self._weights.items():
+            a = np.ascontiguousarray(np.asarray(weights[k], np.float32))
+            if a.shape != v.shape:
+                raise ValueError("%s has shape %s, expected %s" % (k, a.shape, v.shape))
+            self._weights[k] = a
+
+    def output_shape(self, batch):
+        raise NotImplementedError
+
+    def _dev(self, torch, dev, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+    def _check_x(self, x):
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+        if x.ndim != 4 or tuple(x.shape[1:]) != self.input_dims:
+            raise ValueError("expected input of shape [B, %d, %d, %d]" % self.input_dims)
+        return x
+
+    def __call__(self, x):
+        return self.forward(x)
+
+
+class MobileNetV2Block(_HipBlock):
+    """mobilenetV2_block (reference layer_blocks.py:468-550), use_batchnorm=False, dropout 0."""
+
+    def __init__(self, input_dims, filters=32, name=None, seed=42, device=0):
+        if filters <= 0:
+            raise ValueError("Filters should be > 0")
+        c = int(input_dims[2])
+        shapes = {"conv0.w": (1, 1, c, filters), "conv0.b": (filters,), "conv1.w": (3, 3, filters, 1), "conv1.b": (filters,),
+                  "conv2.w": (1, 1, filters, c), "conv2.b": (c,)}
+        super().__init__(name or "mobilenetV2_", input_dims, filters, shapes, seed, device)
+
+    def forward(self, x):
+        torch, dev = self._torch()
+        x = self._check_x(x)
+        b, h, w, c = x.shape
+        f = self.filters
+        xd = self._dev(torch, dev, x)
+        wd = {k: self._dev(torch, dev, v) for k, v in self._weights.items()}
+        t0 = torch.empty((b, h, w, f), dtype=torch.float32, device=dev); t1 = torch.empty_like(t0)
+        u = torch.empty((b, h, w, c), dtype=torch.float32, device=dev); y = torch.empty_like(u)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = self._lib.mvae_mnv2_forward(self._device, p(xd), b, h, w, c, f, p(wd["conv0.w"]), p(wd["conv0.b"]),
+                                         p(wd["conv1.w"]), p(wd["conv1.b"]), p(wd["conv2.w"]), p(wd["conv2.b"]), p(t0), p(t1),
+                                         p(u), p(y), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != _abi.MVAE_OK:
+            raise RuntimeError("mvae_mnv2_forward failed (%d)" % rc)
+        torch.cuda.synchronize(dev)
+        self._saved = dict(x=xd, t0=t0, t1=t1, u=u, w=wd)
+        return y.cpu().numpy()
+
+    def backward(self, dy):
+        """Gradient of sum(y * dy): (dx, {name: gradient}) for the inputs of the last forward()."""
+        if self._saved is None:
+            raise RuntimeError("backward() needs a preceding forward()")
+        torch, dev = self._torch()
+        sv = self._saved
+        b, h, w, c = sv["x"].shape
+        f = self.filters
+        dyd = self._dev(torch, dev, np.asarray(dy, np.float32).reshape(b, h, w, c))
+        dx = torch.empty_like(sv["x"])
+        g = {k: torch.zeros_like(v) for k, v in sv["w"].items()}
+        work = torch.empty(b * h * w * (c + 2 * f) + 64, dtype=torch.float32, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = self._lib.mvae_mnv2_backward(self._device, p(sv["x"]), p(sv["t0"]), p(sv["t1"]), p(sv["u"]), p(dyd), b, h, w, c, f,
+                                          p(sv["w"]["conv0.w"]), p(sv["w"]["conv1.w"]), p(sv["w"]["conv2.w"]), p(dx),
+                                          p(g["conv0.w"]), p(g["conv0.b"]), p(g["conv1.w"]), p(g["conv1.b"]), p(g["conv2.w"]),
+                                          p(g["conv2.b"]), p(work), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != _abi.MVAE_OK:
+            raise RuntimeError("mvae_mnv2_backward failed (%d)" % rc)
+        torch.cuda.synchronize(dev)
+        return dx.cpu().numpy(), {k: v.cpu().numpy() for k, v in g.items()}
+
+
+class ResnetBlock(_HipBlock):
+    """resnet_block (reference layer_blocks.py:789-887), strides (1, 1), use_batchnorm=False, dropout 0."""
+
+    def __init__(self, input_dims, filters=32, kernel_size=(3, 3), strides=(1, 1), activation="relu", name=None, seed=42,
+                 device=0):
+        if filters <= 0:
+            raise ValueError("Filters should be > 0")
+        if tuple(strides) != (1, 1):
+            raise ValueError("the HIP path implements the reference's default strides (1, 1)")
+        if activation not in ("relu", "linear"):
+            raise ValueError("the HIP path implements activation 'relu' (the reference's default) and 'linear'")
+        self.kernel_size = (int(kernel_size[0]), int(kernel_size[1]))
+        self.activation = activation
+        c = int(input_dims[2])
+        kh, kw = self.kernel_size
+        shapes = {"conv0.w": (kh, kw, c, filters), "conv0.b": (filters,), "conv1.w": (kh, kw, filters, filters),
+                  "conv1.b": (filters,)}
+        if c != filters:
+            shapes["skip.w"] = (1, 1, c, filters); shapes["skip.b"] = (filters,)
+        super().__init__(name or "resnet_", input_dims, filters, shapes, seed, device)
+
+    def forward(self, x):
+        torch, dev = self._torch()
+        x = self._check_x(x)
+        b, h, w, c = x.shape
+        f = self.filters
+        kh, kw = self.kernel_size
+        xd = self._dev(torch, dev, x)
+        wd = {k: self._dev(torch, dev, v) for k, v in self._weights.items()}
+        x0 = torch.empty((b, h, w, f), dtype=torch.float32, device=dev)
+        y = torch.empty_like(x0)
+        skip = torch.empty_like(x0) if c != f else None
+        p = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+        rc = self._lib.mvae_resnet_forward(self._device, p(xd), b, h, w, c, f, kh, kw, 1 if self.activation == "relu" else 0,
+                                           p(wd["conv0.w"]), p(wd["conv0.b"]), p(wd["conv1.w"]), p(wd["conv1.b"]),
+                                           p(wd.get("skip.w")), p(wd.get("skip.b")), p(x0), p(skip), p(y),
+                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != _abi.MVAE_OK:
+            raise RuntimeError("mvae_resnet_forward failed (%d)" % rc)
+        torch.cuda.synchronize(dev)
+        self._saved = dict(x=xd, x0=x0, y=y, w=wd)
+        return y.cpu().numpy()
+
+    def backward(self, dy):
+        if self._saved is None:
+            raise RuntimeError("backward() needs a preceding forward()")
+        torch, dev = self._torch()
+        sv = self._saved
+        b, h, w, c = sv["x"].shape
+        f = self.filters
+        kh, kw = self.kernel_size
+        dyd = self._dev(torch, dev, np.asarray(dy, np.float32).reshape(b, h, w, f))
+        dx = torch.empty_like(sv["x"])
+        g = {k: torch.zeros_like(v) for k, v in sv["w"].items()}
+        work = torch.empty(b * h * w * (2 * f + c) + 64, dtype=torch.float32, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+        rc = self._lib.mvae_resnet_backward(self._device, p(sv["x"]), p(sv["x0"]), p(sv["y"]), p(dyd), b, h, w, c, f, kh, kw,
+                                            1 if self.activation == "relu" else 0, p(sv["w"]["conv0.w"]), p(sv["w"]["conv1.w"]),
+                                            p(sv["w"].get("skip.w")), p(dx), p(g["conv0.w"]), p(g["conv0.b"]), p(g["conv1.w"]),
+                                            p(g["conv1.b"]), p(g.get("skip.w")), p(g.get("skip.b")), p(work),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != _abi.MVAE_OK:
+            raise RuntimeError("mvae_resnet_backward failed (%d)" % rc)
+        torch.cuda.synchronize(dev)
+        return dx.cpu().numpy(), {k: v.cpu().numpy() for k, v in g.items()}
+
+
+def mobilenetV2_block(input_dims, filters=32, dropout_ratio=0.0, use_batchnorm=False, prefix="mobilenetV2_",
+                      initializer="glorot_normal", regularizer="l1", channels_index=3):
+    """layer_blocks.py:468-550 with the reference's argument checks; the input is given by its shape (H, W, C)."""
+    if input_dims is None:
+        raise ValueError("input_layer cannot be empty")
+    if filters <= 0:
+        raise ValueError("Filters should be > 0")
+    if dropout_ratio is not None and (dropout_ratio > 1.0 or dropout_ratio < 0.0):
+        raise ValueError("Dropout ration must be [0, 1]")
+    if use_batchnorm or (dropout_ratio or 0.0) > 0.0 or initializer != "glorot_normal":
+        raise ValueError("the HIP path implements the reference's defaults (no BatchNorm, no dropout, glorot_normal)")
+    return MobileNetV2Block(input_dims, filters, name=prefix)
+
+
+def resnet_block(input_dims, filters=32, kernel_size=(3, 3), strides=(1, 1), activation="relu", dropout_ratio=0.0,
+                 use_batchnorm=False, prefix="resnet_", initializer="glorot_normal", regularizer="l1", channels_index=3):
+    """layer_blocks.py:789-887 with the reference's argument checks; the input is given by its shape (H, W, C)."""
+    if input_dims is None:
+        raise ValueError("input_layer cannot be empty")
+    if filters <= 0:
+        raise ValueError("Filters should be > 0")
+    if dropout_ratio is not None and (dropout_ratio > 1.0 or dropout_ratio < 0.0):
+        raise ValueError("Dropout ration must be [0, 1]")
+    if use_batchnorm or (dropout_ratio or 0.0) > 0.0 or initializer != "glorot_normal":
+        raise ValueError("the HIP path implements the reference's defaults (no BatchNorm, no dropout, glorot_normal)")
+    return ResnetBlock(input_dims, filters, kernel_size, strides, activation, name=prefix)

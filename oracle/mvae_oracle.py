@@ -732,3 +732,58 @@ def mobilenetV3_block(x_nhwc, params, training=False, state=None):
 def step_decay(initial_lr, decay_factor, step_size, epoch):
     """schedule.py:17-19."""
     return initial_lr * (decay_factor ** np.floor(epoch / step_size))
+
+
+# ----------------------------------------------------------------------------------------------
+# SURVEY 8(f) rank 4: further blocks of the reference's library, as differentiable torch restatements (test infrastructure
+# for mvae_mnv2_* / mvae_resnet_* of the C ABI).  Defaults as in the reference: use_batchnorm=False, dropout 0.
+# ----------------------------------------------------------------------------------------------
+def block_param_shapes_v2(kind, channels, filters=32, kernel_size=(3, 3)):
+    """'mnv2': mobilenetV2_block (layer_blocks.py:468-550); 'resnet': resnet_block (:789-887) -- tensor name -> shape."""
+    if filters <= 0:
+        raise ValueError("Filters should be > 0")                                     # layer_blocks.py:493-494 / 820-821
+    P = OrderedDict()
+    if kind == "mnv2":
+        P["conv0.w"] = (1, 1, channels, filters); P["conv0.b"] = (filters,)
+        P["conv1.w"] = (3, 3, filters, 1); P["conv1.b"] = (filters,)
+        P["conv2.w"] = (1, 1, filters, channels); P["conv2.b"] = (channels,)
+    elif kind == "resnet":
+        kh, kw = kernel_size
+        P["conv0.w"] = (kh, kw, channels, filters); P["conv0.b"] = (filters,)
+        P["conv1.w"] = (kh, kw, filters, filters); P["conv1.b"] = (filters,)
+        if channels != filters:                                                       # layer_blocks.py:858-872
+            P["skip.w"] = (1, 1, channels, filters); P["skip.b"] = (filters,)
+    else:
+        raise ValueError(kind)
+    return P
+
+
+def mobilenetV2_block_t(x, T):
+    """layer_blocks.py:503-545 on torch tensors (x NCHW, T: name -> tensor): conv0 1x1 linear -> depthwise 3x3 relu ->
+    conv2 1x1 relu back to the input's channels -> Add with the input."""
+    h = conv2d_same(x, T["conv0.w"], T["conv0.b"], (1, 1))
+    h = F.relu(depthwise3x3_same(h, T["conv1.w"], T["conv1.b"]))
+    h = F.relu(conv2d_same(h, T["conv2.w"], T["conv2.b"], (1, 1)))
+    return h + x
+
+
+def resnet_block_t(x, T, activation="relu"):
+    """layer_blocks.py:830-879 at strides (1, 1): conv0 (activation) -> conv1 (linear) -> Add with the input (through a
+    1x1 'skip' convolution when the channel counts differ) -> activation."""
+    act = F.relu if activation == "relu" else (lambda v: v)
+    h = act(conv2d_same(x, T["conv0.w"], T["conv0.b"], (1, 1)))
+    h = conv2d_same(h, T["conv1.w"], T["conv1.b"], (1, 1))
+    skip = conv2d_same(x, T["skip.w"], T["skip.b"], (1, 1)) if "skip.w" in T else x
+    return act(h + skip)
+
+
+def block_forward_backward(kind, x_nhwc, params, dy_nhwc, activation="relu"):
+    """y, dx and the parameter gradients of sum(y * dy) for one stand-alone block, float64."""
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    x = t(x_nhwc).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    T = OrderedDict((k, t(v).clone().requires_grad_(True)) for k, v in params.items())
+    y = mobilenetV2_block_t(x, T) if kind == "mnv2" else resnet_block_t(x, T, activation)
+    loss = (y * t(dy_nhwc).permute(0, 3, 1, 2)).sum()
+    grads = torch.autograd.grad(loss, [x] + list(T.values()))
+    G = OrderedDict((k, g.numpy()) for k, g in zip(T.keys(), grads[1:]))
+    return y.detach().permute(0, 2, 3, 1).numpy(), grads[0].permute(0, 2, 3, 1).numpy(), G

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-2 profile collection on the GPU box (run through gpurun): rocprofv3 kernel stats of the two bench workloads,
+# Profile collection (round 3: O=gpurun_out/r3prof) on the GPU box (run through gpurun): rocprofv3 kernel stats of the two bench workloads,
 # then separate --pmc passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) per MI355X_MICROARCH.md.  Summaries are copied into
 # profiles/ by tools/profiles_summarise.py afterwards (locally).
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-O=gpurun_out/r2prof
+O=gpurun_out/r3prof
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c32 -o c32 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_c32_stats.json 2> $O/bench_c32_stats.err
 echo "stats c32 rc=$?"
