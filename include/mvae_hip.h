@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 2
+#define MVAE_ABI_VERSION 3
 #define MVAE_MAX_LEVELS 16
 #define MVAE_MAX_BLOCKS 16
 #define MVAE_NAME_CAP 96

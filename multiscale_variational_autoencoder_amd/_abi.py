@@ -4,7 +4,7 @@ import os
 
 from ._build import LIB_PATH
 
-MVAE_ABI_VERSION = 2
+MVAE_ABI_VERSION = 3
 MVAE_MAX_LEVELS = 16
 MVAE_MAX_BLOCKS = 16
 MVAE_NAME_CAP = 96
