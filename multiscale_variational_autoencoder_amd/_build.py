@@ -6,8 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmvae_hip.so")
-SOURCES = ["kernels_generic.hip", "kernels_mfma.hip", "kernels_opt.hip", "kernels_edge.hip", "kernels_dw.hip", "kernels_dense.hip", "kernels_se.hip", "kernels_bf16.hip", "kernels_split.hip", "kernels_blocks.hip", "dispatch.hip", "runtime.cpp"]
-HEADERS = ["kernels.h", "act16.h", "prof.h", os.path.join("..", "..", "include", "mvae_hip.h")]
+SOURCES = ["kernels_generic.hip", "kernels_mfma.hip", "kernels_opt.hip", "kernels_edge.hip", "kernels_dw.hip", "kernels_dense.hip", "kernels_se.hip", "kernels_bf16.hip", "kernels_split.hip", "kernels_fused.hip", "kernels_blocks.hip", "dispatch.hip", "runtime.cpp"]
+HEADERS = ["kernels.h", "act16.h", "prof.h", "split.h", os.path.join("..", "..", "include", "mvae_hip.h")]
 
 
 def _hipcc():
@@ -59,8 +59,13 @@ def build_tools(verbose=False):
     """tools/bf16_unit.bin: every bf16 MFMA kernel alone against a double-precision reference (tests/test_bf16_kernels_gpu.py
     runs it on the GPU box; built here because the box has no reason to have a compiler warmed up)."""
     root = os.path.dirname(HERE)
-    src = os.path.join(root, "tools", "bf16_unit.hip")
-    out = os.path.join(root, "tools", "bf16_unit.bin")
+    for name in ("dual_probe.cpp",):                       # timing probes linked against the same objects (not run by tests)
+        _build_tool(os.path.join(root, "tools", name), verbose)
+    return _build_tool(os.path.join(root, "tools", "bf16_unit.hip"), verbose)
+
+
+def _build_tool(src, verbose=False):
+    out = os.path.splitext(src)[0] + ".bin"
     objs = [os.path.join(CSRC, os.path.splitext(s)[0] + ".o") for s in SOURCES if s != "runtime.cpp"]
     deps = [src] + objs
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps if os.path.exists(d)):

@@ -291,6 +291,16 @@ int64_t split_planes_bytes(const ConvGeom& g);                 // workspace for 
 void launch_split_weights(const float* W, void* planes, const ConvGeom& g, hipStream_t s);   // once per layer and step
 bool split_selftest();                 // first call: run the kernels next to a self-checking VALU kernel (see kernels_split.hip)
 int split_conv_erratum_count();        // wrong values the v_pk_fma_f32 form of the self-test's check kernel returned (-1: not run)
+// backward pair of a 64 -> 64 1x1 convolution with split products (kernels_split.hip); false = not covered / switched off
+bool launch_gemm_dual_split(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
+                            float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
+                            GradSlots sl, int dslots, int64_t dstride, int cap, hipStream_t s);
+const char* gemm_dual_split_kernel(bool gated, int64_t M, int64_t rows_per_image, int C);   // its kernel name, or nullptr
+// depthwise backward + conv0 backward pair in one pass (kernels_fused.hip): C = 64, W = 32, H even, mask in the LSB of dt2
+const char* dw_bwd_conv0_split_kernel(int B, int H, int W, int C);                         // kernel name, or nullptr
+bool launch_dw_bwd_conv0_split(const float* dt2, const float* t0, const float* w, const float* gate, const float* dgap,
+                               const float* W0, const float* a_in, const float* dout, float* da, float* dW, float* db,
+                               float* dW0, float* db0, GradSlots sl, int B, int H, int W, int C, hipStream_t s);
 int split_conv_status();               // 0 switched off (MVAE_SPLIT_CONV=0), 1 in use, 2 disabled by the self-test on this board
 bool launch_conv_taps_split(bool transposed, const float* in, const void* planes, const float* bias, float* out,
                             const ConvGeom& g, hipStream_t s);

@@ -1,0 +1,296 @@
+// kernels_fused.hip -- float32 MobileNetV3 backward: the depthwise backward (k_dw_bwd_ring<true, float>, kernels_dw.hip) and
+// conv0's backward pair (k_gemm_dual_s<2>, kernels_split.hip) in ONE pass, so that dt0 -- the depthwise backward's output
+// and the pair's input -- never goes to HBM: 5 tensor passes per block element (dt2, t0, block input, dout in; da out)
+// instead of 7.  The float32 step is bound by its total HBM traffic (every large kernel moves its
+// algorithmic bytes at 4.5-5.2 TB/s, faster kernels did not shorten the step any more), so a pass not made is the lever
+// left.  layer_blocks.py:594-623 inverted; the bf16 counterpart is k16_dw_bwd_conv0 (kernels_bf16.hip).
+//
+// With float32 MFMAs this fusion lost (round 2: 177-182 us against 74 + 100 separately -- 55 us of matrix-core time that
+// did not overlap the ring phase); with split-bf16 products (split.h) the two GEMMs of a row pair are 48 bf16 MFMAs per
+// wave and the kernel is bound by memory again.
+//
+// Shape: C = 64, W = 32 (a row of the image is one 32-pixel MFMA tile, no column halo), H % 4 == 0.  One 512-thread block
+// per CU walks whole images top to bottom:
+//   thread (px = t >> 4, c4 = t & 15) owns one float4 of every row: d1 rows go HBM -> register FIFO -> 4-row LDS ring,
+//   dt0[y] = dwT(d1[y-1 .. y+1]) * (t0[y] > 0) is formed from the ring (3x3 taps), split into three bf16 planes and
+//   written to the row's LDS tile, the block-input row likewise; the depthwise weight / bias gradients accumulate in
+//   registers.  Every two rows the eight waves run the pair's products on the two tiles:
+//     waves 0-3 (row kk, channel tile nt):  da = dt0 . W0^T + dout          24 MFMAs, W0 fragments (pre-split) from LDS
+//     waves 4-7 (ci tile a, co tile b):     P[ci][co] += a^T dt0 over 64 px  24 MFMAs, ds_read_b64_tr_b16 fragments
+// LDS: ring 34 KB + dt0 planes 24 KB + input planes 24 KB + W0 fragments 24 KB + dout rows 16 KB = 122 KB.
+// Rows -1 and H of the ring are stored as zeros, so the tap loops carry no bounds tests: the row loop is straight-line code
+// (counted vmcnt waits).
+#include "kernels.h"
+#include "prof.h"
+#include "split.h"
+#include <cstdlib>
+
+namespace mvae {
+
+namespace {
+constexpr int kFusedRing = 4 * 34 * 16 * 16;     // bytes
+constexpr int kFusedPlane = 32 * 128;            // one bf16 plane of a 32-pixel row
+constexpr int kFusedLds = kFusedRing + 12 * kFusedPlane + 24 * 64 * 16 + 2 * 32 * 64 * 4 + 11 * 16 * 16;
+}
+
+__global__ void __launch_bounds__(512, 1) k_dw_bwd_conv0_s(const f32x4* __restrict__ dt2, const f32x4* __restrict__ t0,
+                                                           const f32x4* __restrict__ w, const f32x4* __restrict__ gate,
+                                                           const f32x4* __restrict__ dgap, const float* __restrict__ W0,
+                                                           const f32x4* __restrict__ a_in, const float* __restrict__ dout,
+                                                           float* __restrict__ da, float* __restrict__ dW,
+                                                           float* __restrict__ db, float* __restrict__ dW0,
+                                                           float* __restrict__ db0, int H, float inv_hw, int B, int nslots,
+                                                           int64_t slot_stride) {
+  constexpr int XSP = 34, TP = kFusedPlane, C = 64;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  f32x4* ring = reinterpret_cast<f32x4*>(lds);                         // [4 slots][34 px][16 quads]: d1, columns 0 / 33 zero
+  char* tD = lds + kFusedRing;                                         // [row kk][plane][4096]: dt0
+  char* tA = tD + 6 * TP;                                              // [row kk][plane][4096]: block input
+  u32x4* wfl = reinterpret_cast<u32x4*>(tA + 6 * TP);                  // [nt][kq][plane][lane]: W0^T fragments
+  float* tR = reinterpret_cast<float*>(tA + 6 * TP + 24 * 64 * 16);    // [row kk][32 px][64]: dout (the residual of da)
+  // depthwise weights [9][16 quads], then the image's gate and dgap / HW: read from LDS at every use -- as registers (44 per
+  // thread) they pushed the kernel over 256 VGPRs and hipcc spilled inside the row loop
+  f32x4* wl = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(tR) + 2 * 32 * 64 * 4);
+  const int px = threadIdx.x >> 4, c4 = threadIdx.x & 15;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+#define RINGF(slot, xs, c4_) ring[((slot) * XSP + (xs)) * 16 + (c4_)]
+  {   // wave w prepares fragment (nt = w >> 2, kq = w & 3): Wt[k = co][n = ci] = W0[ci*64 + co]
+    const int nt = wave >> 2, kq = wave & 3;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(W0 + (int64_t)(nt * 32 + i) * C + kq * 16 + 8 * h);
+    u32x2 a1, a2, a3, b1, b2, b3;
+    split4(__builtin_bit_cast(u32x4, wp[0]), a1, a2, a3);
+    split4(__builtin_bit_cast(u32x4, wp[1]), b1, b2, b3);
+    wfl[((nt * 4 + kq) * 3 + 0) * 64 + lane] = u32x4{a1[0], a1[1], b1[0], b1[1]};
+    wfl[((nt * 4 + kq) * 3 + 1) * 64 + lane] = u32x4{a2[0], a2[1], b2[0], b2[1]};
+    wfl[((nt * 4 + kq) * 3 + 2) * 64 + lane] = u32x4{a3[0], a3[1], b3[0], b3[1]};
+  }
+  if (threadIdx.x < 128) {                                             // columns 0 and 33 of the four slots: always zero
+    const int slot = threadIdx.x >> 5, side = (threadIdx.x >> 4) & 1;
+    RINGF(slot, side ? 33 : 0, c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 aw[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) aw[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (threadIdx.x < 9 * 16) wl[threadIdx.x] = w[threadIdx.x];
+  const f32x4* wlc = wl + c4;
+  f32x4 ab = {0.f, 0.f, 0.f, 0.f}, bs0 = {0.f, 0.f, 0.f, 0.f};
+  f32x16 accw;                                                         // waves 4-7: P tile; waves 0-3: the da tile
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+  const bool gemm_wave = wave < 4;
+  const int ykk = wave & 1, ynt = (wave >> 1) & 1;                     // data-GEMM role: tile row, output-channel tile
+  const int pa = wave & 1, pb = (wave >> 1) & 1;                       // weight-gradient role: ci tile, co tile
+  // every LDS access of the row loop is one of these bases plus a compile-time offset
+  f32x4* rbase = ring + px * 16 + c4;                                  // ring[slot][px + xs][c4] = rbase[(slot*XSP + xs)*16]
+  char* stD = tD + dual_off(px, c4 >> 1) + (c4 & 1) * 8;               // this thread's 8 bytes inside a plane of tD (tA = +6 planes)
+  f32x4* stR = reinterpret_cast<f32x4*>(tR) + px * 16 + c4;
+  const char* gA[4];                                                   // data GEMM: A fragments of the wave's dt0 row, k-step kq
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq) gA[kq] = tD + ykk * 3 * TP + dual_off(i, 2 * kq + h);
+  const u32x4* gW = wfl + ynt * 12 * 64 + lane;
+  const float* gR = tR + (ykk * 32 + 4 * h) * C + ynt * 32 + i;
+  // weight gradient: the two 8-byte pieces of a transposed fragment (rows q and q + 4 of the 16-lane group's 8 rows)
+  const char *pA0, *pA1, *pD0, *pD1;
+  {
+    const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, rb = 8 * (g16 >> 1);
+    const int ca = pa * 32 + 16 * (g16 & 1) + 4 * pp, cd = pb * 32 + 16 * (g16 & 1) + 4 * pp;
+    pA0 = tA + dual_off(rb + q, ca >> 3) + (ca & 7) * 2;
+    pA1 = tA + dual_off(rb + 4 + q, ca >> 3) + (ca & 7) * 2;
+    pD0 = tD + dual_off(rb + q, cd >> 3) + (cd & 7) * 2;
+    pD1 = tD + dual_off(rb + 4 + q, cd >> 3) + (cd & 7) * 2;
+  }
+  auto tr_frag = [](const char* o0, const char* o1) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)o0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)o1);
+    s16x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, f);
+  };
+
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int64_t ioff = (int64_t)b * H * 32 * 16;                     // float4 offset of the image
+    const f32x4 gg_in = gate[(int64_t)b * 16 + c4];
+    const f32x4 dg_in = dgap[(int64_t)b * 16 + c4] * inv_hw;
+    const int yl = H - 1;
+    const f32x4* dout4 = reinterpret_cast<const f32x4*>(dout);
+    auto fetch_row = [&](int y) { return dt2[ioff + ((int64_t)y * 32 + px) * 16 + c4]; };
+    auto store_row = [&](int y, int slot, const f32x4 rd) {            // d1 row y -> ring slot y & 3; rows -1 and H: zeros
+      const bool inside = y >= 0 && y < H;
+      const f32x4 gg_c = wlc[9 * 16], dg_c = wlc[10 * 16];
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned bits = __float_as_uint(rd[q]);
+        v[q] = (inside && (bits & 1u)) ? __uint_as_float(bits & ~1u) * gg_c[q] + dg_c[q] : 0.f;   // ReLU mask t1 > 0 in the LSB
+      }
+      rbase[(slot * XSP + 1) * 16] = v;
+    };
+    auto fetch_t0 = [&](int y) { return t0[ioff + ((int64_t)y * 32 + px) * 16 + c4]; };
+    f32x4 Fd[2], T[2];
+    __syncthreads();                                  // previous image's ring / tile reads are done (and wfl is written)
+    if (threadIdx.x < 16) { wl[9 * 16 + c4] = gg_in; wl[10 * 16 + c4] = dg_in; }
+    Fd[0] = fetch_row(0);
+    Fd[1] = fetch_row(0);
+    T[0] = fetch_t0(0);
+    T[1] = fetch_t0(1);
+    __syncthreads();                                  // gate / dgap of this image are in LDS
+    store_row(-1, 3, Fd[0]);                          // slot 3: zeros
+    store_row(0, 0, Fd[1]);
+    Fd[1] = fetch_row(1);
+    Fd[0] = fetch_row(2);
+    // (unrolling this loop over four rows, to make the ring slots compile-time constants, doubled hipcc's register demand and
+    // spilled 100 registers inside the loop: the slot offsets are run-time values, three pointer adds per row)
+    {
+#pragma unroll 1
+      for (int y2 = 0; y2 < H; y2 += 2) {
+        const int64_t prow = ((int64_t)b * H + y2) * 32;               // pixel index of (y2, 0)
+        const f32x4 la0 = a_in[(prow + px) * 16 + c4];
+        const f32x4 la1 = a_in[(prow + 32 + px) * 16 + c4];
+        const f32x4 lr0 = dout4[(prow + px) * 16 + c4];
+        const f32x4 lr1 = dout4[(prow + 32 + px) * 16 + c4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int y = y2 + kk;
+          store_row(y + 1, (y + 1) & 3, Fd[(kk + 1) & 1]);
+          Fd[(kk + 1) & 1] = fetch_row(min(y + 3, yl));
+          __syncthreads();
+          const f32x4 tvk = T[kk];
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const f32x4* rrow = rbase + ((y - a + 1) & 3) * (XSP * 16);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              const f32x4 sv = rrow[(2 - e) * 16];
+              acc += wlc[(a * 3 + e) * 16] * sv;
+              aw[a * 3 + e] += tvk * sv;
+            }
+          }
+          ab += rbase[((y & 3) * XSP + 1) * 16];
+          f32x4 rv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rv[q] = tvk[q] > 0.f ? acc[q] : 0.f;
+          bs0 += rv;
+          u32x2 p1, p2, p3;
+          split4(__builtin_bit_cast(u32x4, rv), p1, p2, p3);
+          *reinterpret_cast<u32x2*>(stD + (kk * 3 + 0) * TP) = p1;
+          *reinterpret_cast<u32x2*>(stD + (kk * 3 + 1) * TP) = p2;
+          *reinterpret_cast<u32x2*>(stD + (kk * 3 + 2) * TP) = p3;
+          T[kk] = fetch_t0(min(y + 2, yl));
+        }
+        {
+          u32x2 p1, p2, p3;
+          split4(__builtin_bit_cast(u32x4, la0), p1, p2, p3);
+          *reinterpret_cast<u32x2*>(stD + 6 * TP) = p1;                // tA = tD + 6 planes
+          *reinterpret_cast<u32x2*>(stD + 7 * TP) = p2;
+          *reinterpret_cast<u32x2*>(stD + 8 * TP) = p3;
+          split4(__builtin_bit_cast(u32x4, la1), p1, p2, p3);
+          *reinterpret_cast<u32x2*>(stD + 9 * TP) = p1;
+          *reinterpret_cast<u32x2*>(stD + 10 * TP) = p2;
+          *reinterpret_cast<u32x2*>(stD + 11 * TP) = p3;
+          stR[0] = lr0;
+          stR[32 * 16] = lr1;
+        }
+        __syncthreads();                              // all tiles of the row pair complete
+        if (gemm_wave) {
+          // ---- da tile: row y2 + ykk, output channels 32 ynt ..   (A = dt0 rows, B = W0^T fragments)
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) {
+            bf16x8 xa[3], wb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              xa[p] = as_frag(*reinterpret_cast<const u32x4*>(gA[kq] + p * TP));
+              wb[p] = as_frag(gW[(kq * 3 + p) * 64]);
+            }
+            MVAE_SPLIT6(acc, xa, wb);
+          }
+          float* py = da + (prow + ykk * 32 + 4 * h) * C + ynt * 32 + i;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) py[((r & 3) + 8 * (r >> 2)) * C] = acc[r] + gR[((r & 3) + 8 * (r >> 2)) * C];
+        } else {
+          // ---- P[ci][co] += a^T dt0 over the 64 pixels of the pair
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              bf16x8 fa[3], fb[3];
+#pragma unroll
+              for (int p = 0; p < 3; ++p) {
+                fa[p] = tr_frag(pA0 + (kk * 3 + p) * TP + half * 2048, pA1 + (kk * 3 + p) * TP + half * 2048);
+                fb[p] = tr_frag(pD0 + (kk * 3 + p) * TP + half * 2048, pD1 + (kk * 3 + p) * TP + half * 2048);
+              }
+              MVAE_SPLIT6(accw, fa, fb);
+            }
+        }
+      }
+    }
+  }
+  // ---- depthwise weight / bias gradients and db0: lanes l, l + 16, l + 32, l + 48 share the channel quad
+  __syncthreads();
+  f32x4* red = reinterpret_cast<f32x4*>(tD);                           // [8 waves][11][16 quads] = 22.5 KB <= tD + tA
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    f32x4 v = k < 9 ? aw[k < 9 ? k : 0] : (k == 9 ? ab : bs0);
+    for (int off = 16; off < 64; off <<= 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += __shfl_xor(v[q], off, 64);
+    }
+    if (lane < 16) red[(wave * 11 + k) * 16 + lane] = v;
+  }
+  __syncthreads();
+  const int64_t slot = (int64_t)(blockIdx.x % nslots) * slot_stride;
+  for (int idx = threadIdx.x; idx < 11 * 64; idx += 512) {
+    const int q = idx & 3, cc = (idx >> 2) & 15, k = idx >> 6;
+    float t = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 8; ++wv) t += red[(wv * 11 + k) * 16 + cc][q];
+    float* dst = k < 9 ? dW + slot + (int64_t)k * 64 : (k == 9 ? db + slot : (db0 ? db0 + slot : nullptr));
+    if (dst) atomicAdd(dst + cc * 4 + q, t);
+  }
+  // ---- conv0 weight gradient: the four P tiles through LDS (dW0[ci][co] row-major), one coalesced atomic set per block
+  __syncthreads();
+  float* redw = reinterpret_cast<float*>(lds);                         // 16 KB of the ring
+  if (!gemm_wave) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = pa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, co = pb * 32 + i;
+      redw[ci * 64 + co] = accw[r];
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 512) atomicAdd(&dW0[slot + idx], redw[idx]);
+#undef RINGF
+}
+
+// dt2 (float32, ReLU mask of t1 in the mantissa LSB) -> da, dW_dw, db_dw, dW0, db0.  false = shape not covered or switched
+// off (the caller then runs launch_dw_bwd_fused and launch_gemm_dual_mfma).
+const char* dw_bwd_conv0_split_kernel(int B, int H, int W, int C) {
+  static const bool on = [] { const char* e = getenv("MVAE_FUSE_DW_CONV0_F32"); return e ? atoi(e) != 0 : true; }();
+  if (!on || split_conv_status() != 1) return nullptr;
+  if (C != 64 || W != 32 || H % 4 != 0 || H < 4 || B < 1) return nullptr;
+  if ((int64_t)B * H * W >= (1LL << 31) / 64) return nullptr;
+  return "k_dw_bwd_conv0_s";
+}
+bool launch_dw_bwd_conv0_split(const float* dt2, const float* t0, const float* w, const float* gate, const float* dgap,
+                               const float* W0, const float* a_in, const float* dout, float* da, float* dW, float* db,
+                               float* dW0, float* db0, GradSlots sl, int B, int H, int W, int C, hipStream_t s) {
+  if (!dw_bwd_conv0_split_kernel(B, H, W, C)) return false;
+  static const bool attr = hipFuncSetAttribute((const void*)k_dw_bwd_conv0_s, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               kFusedLds) == hipSuccess;
+  if (!attr) return false;
+  static const int cus = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  int grid = B < cus ? B : cus;
+  if (det_mode() && grid > kDetSlots) grid = kDetSlots;
+  hipLaunchKernelGGL(k_dw_bwd_conv0_s, dim3(grid), dim3(512), kFusedLds, s, (const f32x4*)dt2, (const f32x4*)t0,
+                     (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, W0, (const f32x4*)a_in, dout, da, sl.at(dW),
+                     sl.at(db), sl.at(dW0), sl.at(db0), H, 1.0f / (float)(H * W), B, sl.count(), sl.stride);
+  return true;
+}
+
+}  // namespace mvae

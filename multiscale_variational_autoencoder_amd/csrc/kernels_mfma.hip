@@ -1316,6 +1316,8 @@ static void run_gemm_dual(const float* X, const float* W, const float* aux, cons
   constexpr int TR = 32 * (4 / (C / 32));
   int64_t ntiles = (M + TR - 1) / TR;
   const int cap = 2 * big_grid_cus();                      // 2 resident blocks per CU
+  if (C == 64 && launch_gemm_dual_split(X, W, aux, gate, residual, Y, dW, db, dot_out, M, rpi, C, sl, dslots, dstride, cap, s))
+    return;
   int grid = (int)(ntiles < cap ? ntiles : cap);
 #define MVAE_DUAL(MODE)                                                                                              \
   hipLaunchKernelGGL((k_gemm_dual<C, MODE>), dim3(grid), dim3(256), 0, s, X, W, aux, gate, residual, Y, sl.at(dW),   \

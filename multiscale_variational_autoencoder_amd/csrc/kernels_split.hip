@@ -17,65 +17,11 @@
 // (k_split_weights); activations are split by the wave that gathers them, on their way into its LDS tile.
 #include "kernels.h"
 #include "prof.h"
+#include "split.h"
 #include <cstdio>
 #include <cstdlib>
 
 namespace mvae {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-namespace {
-
-__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-
-// Row-major planes of bf16 rows (pixels of the A tile, output channels of a weight slice), 2 C bytes per row, with the
-// 16-byte chunks of a row XOR-swizzled for gfx950's ds_read_b128: that instruction is served in four 16-lane groups
-// {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) over 64 banks = sixteen 16-byte slots per 256 bytes (MI355X_MICROARCH.md,
-// LDS), and the fragment reads put lane l on row l & 31.  128-byte rows: two rows per 256 bytes, the eight rows of a group
-// with the same parity have distinct (row >> 1) & 7.  64-byte rows: four rows per 256 bytes, the four rows of a group in
-// the same residue class mod 4 have distinct (row >> 2) & 3.  (kernels_bf16.hip's tile_off -- row & 7 / pairs of rows --
-// is 2-way conflicted for these groups: SQ_LDS_BANK_CONFLICT was 33 % of the LDS cycles of the first version here.)
-// 8-byte stores by 16 contiguous lanes cover whole 128-byte runs in either layout.
-template <int C>
-__device__ __host__ __forceinline__ int row_off(int row, int chunk) {
-  if constexpr (C == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-  else return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
-}
-template <int C>
-__device__ __forceinline__ int tile_off(int row, int chunk) { return row_off<C>(row, chunk); }
-template <int KC>
-__device__ __host__ __forceinline__ int wrow_off(int n, int chunk) { return row_off<KC>(n, chunk); }
-
-// (lo 16 bits = high half of a, hi 16 bits = high half of b): two truncated bf16 in one v_perm_b32
-__device__ __forceinline__ unsigned hi16_pair(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-
-// four float32 -> three bf16 planes (4 bf16 = 8 bytes each), exact: x = p1 + p2 + p3.  Per pair of floats: one v_perm_b32
-// packs the two high halves (the truncated bf16), two v_and_b32 rebuild them as floats, one v_pk_add_f32 takes both
-// residuals -- 9 VALU instructions per pair for the three planes (the split is this kernel's VALU load: ~100 instructions
-// per tap next to its 24 MFMAs).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split4(const u32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
-  unsigned r1[4], r2[4];
-#pragma unroll
-  for (int e = 0; e < 4; e += 2) {
-    const f32x2 x = {__uint_as_float(v[e]), __uint_as_float(v[e + 1])};
-    const f32x2 hx = {__uint_as_float(v[e] & 0xFFFF0000u), __uint_as_float(v[e + 1] & 0xFFFF0000u)};
-    const f32x2 a = x - hx;                                                        // exact (<= 16 significant bits)
-    r1[e] = __float_as_uint(a[0]); r1[e + 1] = __float_as_uint(a[1]);
-    const f32x2 ha = {__uint_as_float(r1[e] & 0xFFFF0000u), __uint_as_float(r1[e + 1] & 0xFFFF0000u)};
-    const f32x2 b = a - ha;                                                        // exact (<= 8 significant bits)
-    r2[e] = __float_as_uint(b[0]); r2[e + 1] = __float_as_uint(b[1]);
-  }
-  p1 = u32x2{hi16_pair(v[0], v[1]), hi16_pair(v[2], v[3])};
-  p2 = u32x2{hi16_pair(r1[0], r1[1]), hi16_pair(r1[2], r1[3])};
-  p3 = u32x2{hi16_pair(r2[0], r2[1]), hi16_pair(r2[2], r2[3])};
-}
-
-}  // namespace
 
 // ---- weights -> bf16 planes in the kernels' LDS layout ------------------------------------------------------------
 // W: [taps][CI][CO] float32 (F-form coordinates: a Conv2D kernel HWIO, or a Conv2DTranspose kernel (kh,kw,out,in)).
@@ -563,6 +509,247 @@ void launch_split_weights(const float* W, void* planes, const ConvGeom& g, hipSt
   char* pF = static_cast<char*>(planes);
   char* pT = pF + (int64_t)taps * 3 * g.CI * g.CO * 2;
   hipLaunchKernelGGL(k_split_weights, dim3((n + 255) / 256), dim3(256), 0, s, W, pF, pT, taps, g.CI, g.CO);
+}
+
+// =================================================================================================
+// The backward pair of a 1x1 convolution 64 -> 64 of the MobileNetV3 block (k_gemm_dual<64, 1 / 2>, kernels_mfma.hip) with
+// split products.  The float32 kernel spends 55 us of matrix-core time per launch at M = 2^19 next to 77 us of memory time
+// (AI 21 FLOP/B needs 70 % of the float32 MFMA peak at 5.2 TB/s): the two do not overlap that well and it runs at 3.9 TB/s.
+// Here a tile is 48 bf16 MFMAs per wave (1536 cycles instead of 4096) plus ~230 VALU instructions per thread for the split,
+// which each thread does ONCE on the 32 values it stages (the same element is an MFMA operand of two waves).
+//   block tile 64 rows, waves = 2 row groups x 2 column groups as in k_gemm_dual; LDS: three bf16 planes of X and of
+//   (gated) aux, [plane][row][64 channels], 16-byte chunks XOR-swizzled with a pattern that is conflict-free both for the
+//   row-major ds_read_b128 fragments (data GEMM, A operand) and for the ds_read_b64_tr_b16 fragments (weight gradient,
+//   both operands pixel-major); MODE 1 keeps the raw float32 aux tile as well (ReLU mask + gate-gradient dot in the epilogue).
+//   Wt planes live in registers (48).  Epilogue, residual prefetch, slots: as k_gemm_dual.  db = column sums of the values
+//   a thread stages (its four float4 share the channel quad), folded once at the end.
+// M % 64 == 0, rows_per_image a power of two >= 64 (a tile lies in one image: one gate vector, one dot atomic per wave).
+// =================================================================================================
+
+#ifndef MVAE_DUAL_VARIANT
+#define MVAE_DUAL_VARIANT 0        /* tools/dual_variants.sh: 1 no weight gradient, 2 no data GEMM, 3 no split arithmetic, 4 plain epilogue, 5 no tile loads */
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) k_gemm_dual_s(const float* __restrict__ X, const float* __restrict__ W,
+                                                        const float* __restrict__ aux, const float* __restrict__ gate,
+                                                        const float* __restrict__ residual, float* __restrict__ Y,
+                                                        float* __restrict__ dW, float* __restrict__ db,
+                                                        float* __restrict__ dot_out, int64_t M, int rpi_shift, int nslots,
+                                                        int64_t slot_stride, int dslots, int64_t dstride) {
+  constexpr int C = 64, C4 = 16, TR = 64, LD = 4, PL = TR * C * 2;          // PL = bytes of one plane
+  __shared__ __attribute__((aligned(16))) char lds[6 * PL + (MODE == 1 ? TR * C * 4 : 0)];
+  char* pX = lds;
+  char* pA = lds + 3 * PL;
+  float* sA = reinterpret_cast<float*>(lds + 6 * PL);                      // MODE 1: raw aux (t1), float32, SWZ layout
+  if (MODE == 1) dot_out += (int64_t)(blockIdx.x % dslots) * dstride;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = wave & 1, rw = wave >> 1, n0 = nw * 32;
+  const int i = lane & 31, h = lane >> 5;
+  const int sr = threadIdx.x >> 4, sc4 = threadIdx.x & 15;                 // staging: rows sr + 16 j, channel quad sc4
+  // raw aux tile: plain row-major (one address register for the 16 epilogue reads; the two lane halves read rows 4 apart,
+  // i.e. the same banks: 2 cycles per ds_read_b32 instead of 1, against ~15 registers of swizzled addresses)
+#define SWZ4(r, c4) ((r) * C4 + (c4))
+#define SWZ1(r, c) ((r) * C + (c))
+  // Wt[k][n = n0 + i] = W[n * 64 + k], k = kk*16 + 8h + j: three planes per k-step, resident
+  bf16x8 wreg[4][3];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(W + (int64_t)(n0 + i) * C + kk * 16 + 8 * h);
+    u32x2 a1, a2, a3, b1, b2, b3;
+    split4(__builtin_bit_cast(u32x4, wp[0]), a1, a2, a3);
+    split4(__builtin_bit_cast(u32x4, wp[1]), b1, b2, b3);
+    wreg[kk][0] = as_frag(u32x4{a1[0], a1[1], b1[0], b1[1]});
+    wreg[kk][1] = as_frag(u32x4{a2[0], a2[1], b2[0], b2[1]});
+    wreg[kk][2] = as_frag(u32x4{a3[0], a3[1], b3[0], b3[1]});
+  }
+  const int64_t ntiles = M / TR;
+  const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
+  const f32x4* A4 = reinterpret_cast<const f32x4*>(aux);
+  f32x16 accw[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[kt][r] = 0.f;
+  f32x4 bs4 = {0.f, 0.f, 0.f, 0.f};
+  struct Stage { f32x4 x[LD], a[LD], g; };                 // g: the tile's image gate (a 64-row tile lies in one image)
+  Stage S;
+  auto load_tile = [&](int64_t tile) {
+    const f32x4* px = X4 + tile * (TR * C4) + threadIdx.x;
+    const f32x4* pa = A4 + tile * (TR * C4) + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < LD; ++j) { S.x[j] = px[j * 256]; S.a[j] = pa[j * 256]; }
+    if constexpr (MODE == 1)
+      S.g = reinterpret_cast<const f32x4*>(gate)[(int64_t)((uint32_t)(tile * TR) >> rpi_shift) * C4 + sc4];
+  };
+  float res[16];
+  auto load_res = [&](int64_t tile) {
+    const float* pr = residual + (tile * TR + rw * 32 + 4 * h) * C + n0 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = pr[((r & 3) + 8 * (r >> 2)) * C];
+  };
+  int64_t tile = blockIdx.x;
+  const int64_t g1 = gridDim.x;
+  if (tile < ntiles) {
+    load_tile(tile);
+    if constexpr (MODE == 2) load_res(tile);
+  }
+  for (; tile < ntiles; tile += g1) {
+    const int64_t row0 = tile * TR + rw * 32;
+    const int64_t next = tile + g1 < ntiles ? tile + g1 : tile;
+    __syncthreads();                                       // previous tile fully consumed by all waves
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+      const int r = sr + 16 * j;
+      const int off = dual_off(r, sc4 >> 1) + (sc4 & 1) * 8;
+      u32x2 p1, p2, p3;
+#if MVAE_DUAL_VARIANT == 3
+#define split4(V, A, B_, C_) do { const u32x4 v_ = (V); A = u32x2{v_[0], v_[1]}; B_ = u32x2{v_[2], v_[3]}; C_ = u32x2{v_[1], v_[2]}; } while (0)
+#endif
+      split4(__builtin_bit_cast(u32x4, S.x[j]), p1, p2, p3);
+      *reinterpret_cast<u32x2*>(pX + off) = p1;
+      *reinterpret_cast<u32x2*>(pX + PL + off) = p2;
+      *reinterpret_cast<u32x2*>(pX + 2 * PL + off) = p3;
+      bs4 += S.x[j];
+      f32x4 a = S.a[j];
+      if constexpr (MODE == 1) {
+        reinterpret_cast<f32x4*>(sA)[SWZ4(r, sc4)] = a;
+        a = a * S.g;
+      }
+      split4(__builtin_bit_cast(u32x4, a), p1, p2, p3);
+      *reinterpret_cast<u32x2*>(pA + off) = p1;
+      *reinterpret_cast<u32x2*>(pA + PL + off) = p2;
+      *reinterpret_cast<u32x2*>(pA + 2 * PL + off) = p3;
+#if MVAE_DUAL_VARIANT == 3
+#undef split4
+#endif
+    }
+    __syncthreads();
+#if MVAE_DUAL_VARIANT != 5
+    load_tile(next);                                       // prefetch under the MFMAs (past the end: refetch, unused)
+#endif
+    const int64_t ebase = (row0 + 4 * h) * C + n0 + i;
+    // ---- Y tile = X . Wt (32 rows x 32 columns per wave), then dW[:, n0..n0+31] += (aux * gate)^T X over the wave's 32 rows.
+    // The LDS fragments of a phase are requested one phase ahead of its MFMAs (sched_barrier keeps hipcc from sinking the
+    // reads next to their first use, where every group of MFMAs waited for its own ds_read).
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr bool kData = MVAE_DUAL_VARIANT != 2, kWgrad = MVAE_DUAL_VARIANT != 1;
+    bf16x8 xa[4][3], fa[2][2][3], fb[2][3];
+    auto read_x = [&](int kk) {
+      const int off = dual_off(rw * 32 + i, 2 * kk + h);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) xa[kk][p] = as_frag(*reinterpret_cast<const u32x4*>(pX + p * PL + off));
+    };
+    auto read_b = [&](int sidx) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fb[sidx][p] = dual_frag_cols(pX + p * PL, lane, rw * 32, nw, sidx);
+    };
+    auto read_a = [&](int sidx, int kt) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fa[sidx][kt][p] = dual_frag_cols(pA + p * PL, lane, rw * 32, kt, sidx);
+    };
+#define MVAE_SB() __builtin_amdgcn_sched_barrier(0)
+    // at most 12 fragments (48 registers) requested or waiting at any time
+    if (kData) { read_x(0); read_x(1); }
+    MVAE_SB();
+    if (kData) { read_x(2); read_x(3); MVAE_SPLIT6(acc, xa[0], wreg[0]); MVAE_SPLIT6(acc, xa[1], wreg[1]); }
+    MVAE_SB();
+    if (kWgrad) { read_b(0); read_a(0, 0); }
+    if (kData) { MVAE_SPLIT6(acc, xa[2], wreg[2]); MVAE_SPLIT6(acc, xa[3], wreg[3]); }
+    MVAE_SB();
+    if (kWgrad) { read_a(0, 1); read_b(1); MVAE_SPLIT6(accw[0], fa[0][0], fb[0]); }
+    MVAE_SB();
+    if (kWgrad) { read_a(1, 0); MVAE_SPLIT6(accw[1], fa[0][1], fb[0]); }
+    MVAE_SB();
+    float av[16];                                          // MODE 1: raw aux in the accumulator layout (mask + dot)
+    if (kWgrad) { read_a(1, 1); MVAE_SPLIT6(accw[0], fa[1][0], fb[1]); }
+    MVAE_SB();
+    if (kWgrad) { MVAE_SPLIT6(accw[1], fa[1][1], fb[1]); }
+    if constexpr (MODE == 1 && MVAE_DUAL_VARIANT != 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) av[r] = sA[SWZ1(rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + i)];
+    }
+    MVAE_SB();
+#undef MVAE_SB
+    // ---- epilogue straight from the accumulator layout
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += res[r];
+      load_res(next);                                      // ahead of the stores (k_gemm_dual's header comment)
+    }
+    float* py = Y + ebase;
+    if constexpr (MODE == 1 && MVAE_DUAL_VARIANT != 4) {
+      float dsum = 0.f;                                    // the wave's 32 rows lie in one image
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dsum += acc[r] * av[r];
+        py[((r & 3) + 8 * (r >> 2)) * C] = __uint_as_float((__float_as_uint(acc[r]) & ~1u) | (av[r] > 0.f ? 1u : 0u));
+      }
+      dsum += __shfl_xor(dsum, 32, 64);
+      if (h == 0) atomicAdd(dot_out + (int64_t)((uint32_t)row0 >> rpi_shift) * C + n0 + i, dsum);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) py[((r & 3) + 8 * (r >> 2)) * C] = acc[r];
+    }
+  }
+  // ---- reduce the row groups' dW slabs through LDS, then one coalesced float-atomic set per block
+  float* red = reinterpret_cast<float*>(lds);              // C*C floats = 16 KB <= the X planes
+  for (int step = 0; step < 2; ++step) {
+    __syncthreads();
+    if (rw == step) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int idx = ci * C + n0 + i;
+          red[idx] = (step == 0 ? 0.f : red[idx]) + accw[kt][r];
+        }
+    }
+  }
+  f32x4* redb = reinterpret_cast<f32x4*>(pA);              // [16 staging rows][16 channel quads]
+  redb[sr * C4 + sc4] = bs4;
+  __syncthreads();
+  const int64_t slot = (int64_t)(blockIdx.x % nslots) * slot_stride;
+  for (int idx = threadIdx.x; idx < C * C; idx += 256) atomicAdd(&dW[slot + idx], red[idx]);
+  if (db != nullptr && threadIdx.x < C) {
+    const float* rb = reinterpret_cast<const float*>(pA);
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += rb[q * C + threadIdx.x];
+    atomicAdd(&db[slot + threadIdx.x], t);
+  }
+#undef SWZ4
+#undef SWZ1
+}
+
+static bool dual_split_enabled() {
+  static const bool on = [] { const char* e = getenv("MVAE_SPLIT_DUAL"); return e ? atoi(e) != 0 : true; }();
+  return on && split_enabled();
+}
+// which kernel launch_gemm_dual_split would run for this shape (profile tags); nullptr = not covered
+const char* gemm_dual_split_kernel(bool gated, int64_t M, int64_t rows_per_image, int C) {
+  if (!dual_split_enabled() || g_split_state == 2) return nullptr;
+  if (C != 64 || M % 64 != 0 || M >= (1LL << 31)) return nullptr;
+  if (rows_per_image < 64 || (rows_per_image & (rows_per_image - 1)) != 0) return nullptr;      // a 64-row tile lies in one image
+  return gated ? "k_gemm_dual_s<1>" : "k_gemm_dual_s<2>";
+}
+// conv2 pair (gate + dot_out, no residual) or conv0 pair (residual, no gate / dot) of a 64 -> 64 1x1 convolution
+bool launch_gemm_dual_split(const float* X, const float* W, const float* aux, const float* gate, const float* residual,
+                            float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
+                            GradSlots sl, int dslots, int64_t dstride, int cap, hipStream_t s) {
+  const bool m1 = gate && dot_out && !residual, m2 = residual && !gate && !dot_out;
+  if (!(m1 || m2) || !gemm_dual_split_kernel(m1, M, rows_per_image, C)) return false;
+  const int64_t ntiles = M / 64;
+  const int grid = (int)(ntiles < cap ? ntiles : cap);
+  const int sh = 63 - __builtin_clzll((unsigned long long)rows_per_image);
+#define MVAE_DS(MODE)                                                                                                  \
+  hipLaunchKernelGGL((k_gemm_dual_s<MODE>), dim3(grid), dim3(256), 0, s, X, W, aux, gate, residual, Y, sl.at(dW), sl.at(db), \
+                     dot_out, M, sh, sl.count(), sl.stride, dslots < 1 ? 1 : dslots, dstride)
+  if (m1) MVAE_DS(1); else MVAE_DS(2);
+#undef MVAE_DS
+  return true;
 }
 
 // F-form (in = big) / T-form (in = small) k x k convolution from pre-split weight planes.  false = shape not covered.

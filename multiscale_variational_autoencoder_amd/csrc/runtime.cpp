@@ -731,7 +731,8 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   }
   bool dual2;
   {
-    ProfScope ps(c == 64 ? "k_gemm_dual<64, 1>" : "k_gemm_dual<32, 1>", 12.0 * B * HW * c, 4.0 * B * HW * c * c, s);   // rocprof kernel names
+    const char* stag = gemm_dual_split_kernel(true, (int64_t)B * HW, HW, c);
+    ProfScope ps(stag ? stag : (c == 64 ? "k_gemm_dual<64, 1>" : "k_gemm_dual<32, 1>"), 12.0 * B * HW * c, 4.0 * B * HW * c * c, s);   // rocprof kernel names
     // dt2 = dout . W2^T ; dW2 += (t1*g)^T dout ; db2 ; dg = sum_hw dt2 * t1     -- one pass over (dout, t1)
     dual2 = launch_gemm_dual_mfma(dout, P + m.w2, m.t1, m.g, nullptr, bufB, G + m.w2, G + m.b2, dg, (int64_t)B * HW, HW,
                                   c, h->gslots, m.dg_slots, dg_stride, s);
@@ -769,6 +770,16 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   }
   // through the gate multiply, the global average pool and the depthwise ReLU
   float* bufC = acquire(h, sc, s);
+  if (dual2 && h->lsb_mask && dw_bwd_conv0_split_kernel(B, m.H, m.W, c)) {
+    // ... and conv0's backward pair in the same pass: dt0 is never stored (kernels_fused.hip)
+    ProfScope ps("k_dw_bwd_conv0_s", 20.0 * B * HW * c, (40.0 + 4.0 * c) * B * HW * c, s);
+    if (launch_dw_bwd_conv0_split(bufB, m.t0, P + m.wd, m.g, sc.dgap, P + m.w0, x, dout, bufC, G + m.wd, G + m.bd, G + m.w0,
+                                  G + m.b0, h->gslots, B, m.H, m.W, c, s)) {
+      release(sc, bufB);
+      release(sc, dout);
+      return bufC;
+    }
+  }
   bool fused_dw;
   {
     const bool lsb = dual2 && h->lsb_mask;
@@ -785,7 +796,8 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   }
   bool dual0;
   {
-    ProfScope ps(c == 64 ? "k_gemm_dual<64, 2>" : "k_gemm_dual<32, 2>", 16.0 * B * HW * c, 4.0 * B * HW * c * c, s);
+    const char* stag = gemm_dual_split_kernel(false, (int64_t)B * HW, HW, c);
+    ProfScope ps(stag ? stag : (c == 64 ? "k_gemm_dual<64, 2>" : "k_gemm_dual<32, 2>"), 16.0 * B * HW * c, 4.0 * B * HW * c * c, s);
     // da = dt0pre . W0^T + dout ; dW0 += a^T dt0pre ; db0     -- one pass over (dt0pre, a, dout)
     dual0 = launch_gemm_dual_mfma(bufC, P + m.w0, x, nullptr, dout, bufB, G + m.w0, G + m.b0, nullptr, (int64_t)B * HW, HW,
                                   c, h->gslots, 1, 0, s);
@@ -1142,6 +1154,7 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   {   // a plan with split-bf16 convolutions: once per process, check that this board runs them cleanly (kernels_split.hip)
     bool wants = false;
     for (Scale& sc : h->scales) {
+      wants = wants || (!sc.bf && split_conv_status() != 0);      // float32 scales: the 1x1 backward pairs (k_gemm_dual_s)
       for (Block& b : sc.enc) wants = wants || b.wsplit;
       for (Block& b : sc.dec) wants = wants || b.wsplit;
     }

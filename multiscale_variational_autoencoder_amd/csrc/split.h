@@ -1,0 +1,93 @@
+// split.h -- shared device helpers of the split-bf16 kernels (kernels_split.hip, kernels_fused.hip): exact three-way bf16
+// split of float32 values, the swizzled LDS plane layouts and their fragment reads, the six-MFMA product.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mvae {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// Row-major planes of bf16 rows (pixels of the A tile, output channels of a weight slice), 2 C bytes per row, with the
+// 16-byte chunks of a row XOR-swizzled for gfx950's ds_read_b128: that instruction is served in four 16-lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) over 64 banks = sixteen 16-byte slots per 256 bytes (MI355X_MICROARCH.md,
+// LDS), and the fragment reads put lane l on row l & 31.  128-byte rows: two rows per 256 bytes, the eight rows of a group
+// with the same parity have distinct (row >> 1) & 7.  64-byte rows: four rows per 256 bytes, the four rows of a group in
+// the same residue class mod 4 have distinct (row >> 2) & 3.  (kernels_bf16.hip's tile_off -- row & 7 / pairs of rows --
+// is 2-way conflicted for these groups: SQ_LDS_BANK_CONFLICT was 33 % of the LDS cycles of the first version here.)
+// 8-byte stores by 16 contiguous lanes cover whole 128-byte runs in either layout.
+template <int C>
+__device__ __host__ __forceinline__ int row_off(int row, int chunk) {
+  if constexpr (C == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  else return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+template <int C>
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row_off<C>(row, chunk); }
+template <int KC>
+__device__ __host__ __forceinline__ int wrow_off(int n, int chunk) { return row_off<KC>(n, chunk); }
+
+// (lo 16 bits = high half of a, hi 16 bits = high half of b): two truncated bf16 in one v_perm_b32
+__device__ __forceinline__ unsigned hi16_pair(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// four float32 -> three bf16 planes (4 bf16 = 8 bytes each), exact: x = p1 + p2 + p3.  Per pair of floats: one v_perm_b32
+// packs the two high halves (the truncated bf16), two v_and_b32 rebuild them as floats, one v_pk_add_f32 takes both
+// residuals -- 9 VALU instructions per pair for the three planes (the split is this kernel's VALU load: ~100 instructions
+// per tap next to its 24 MFMAs).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4(const u32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
+  unsigned r1[4], r2[4];
+#pragma unroll
+  for (int e = 0; e < 4; e += 2) {
+    const f32x2 x = {__uint_as_float(v[e]), __uint_as_float(v[e + 1])};
+    const f32x2 hx = {__uint_as_float(v[e] & 0xFFFF0000u), __uint_as_float(v[e + 1] & 0xFFFF0000u)};
+    const f32x2 a = x - hx;                                                        // exact (<= 16 significant bits)
+    r1[e] = __float_as_uint(a[0]); r1[e + 1] = __float_as_uint(a[1]);
+    const f32x2 ha = {__uint_as_float(r1[e] & 0xFFFF0000u), __uint_as_float(r1[e + 1] & 0xFFFF0000u)};
+    const f32x2 b = a - ha;                                                        // exact (<= 8 significant bits)
+    r2[e] = __float_as_uint(b[0]); r2[e + 1] = __float_as_uint(b[1]);
+  }
+  p1 = u32x2{hi16_pair(v[0], v[1]), hi16_pair(v[2], v[3])};
+  p2 = u32x2{hi16_pair(r1[0], r1[1]), hi16_pair(r1[2], r1[3])};
+  p3 = u32x2{hi16_pair(r2[0], r2[1]), hi16_pair(r2[2], r2[3])};
+}
+
+}  // namespace
+
+
+namespace {
+__device__ __forceinline__ int dual_off(int row, int chunk) {       // byte offset inside one 64-row plane
+  return row * 128 + ((chunk ^ ((((row >> 1) & 3) << 1) | ((row >> 3) & 1))) << 4);
+}
+// transposed fragment from a plane: channel ct*32 + (lane & 31), rows rbase + 16 s + 8 (lane >> 5) .. + 7
+__device__ __forceinline__ bf16x8 dual_frag_cols(const char* plane, int lane, int rbase, int ct, int s) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int c0 = ct * 32 + 16 * (g & 1) + 4 * p;
+  const int rb = rbase + 16 * s + 8 * (g >> 1);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int o0 = dual_off(rb + q, c0 >> 3) + (c0 & 7) * 2;
+  const int o1 = dual_off(rb + 4 + q, c0 >> 3) + (c0 & 7) * 2;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane + o0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane + o1));
+  s16x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, f);
+}
+#define MVAE_SPLIT6(ACC, A, B)                                                         \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[0], ACC, 0, 0, 0);             \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], ACC, 0, 0, 0);             \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[2], ACC, 0, 0, 0);             \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], ACC, 0, 0, 0);             \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], ACC, 0, 0, 0);             \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], ACC, 0, 0, 0)
+}  // namespace
+
+}  // namespace mvae
