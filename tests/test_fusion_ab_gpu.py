@@ -1,6 +1,8 @@
 """GPU: the fused launches against the launches they replace.  The switches are read once per process
 (MVAE_FUSE_PW_CHAIN: conv2 + next block's conv0 in one launch, float32 and bf16; MVAE_FUSE_DW_CONV0: depthwise
-backward + conv0's backward pair, bf16), so each variant runs in a subprocess.  Fused and separate launches round at
+backward + conv0's backward pair, bf16; MVAE_FUSE_DW_CONV0_F32: the same pass in float32 on split-bf16 products, 32- and
+16-wide maps; MVAE_SPLIT_DUAL: the 1x1 backward pairs on split-bf16 products instead of float32 MFMAs), so each variant
+runs in a subprocess.  Fused and separate launches round at
 the same points; what differs between two runs is what differs between ANY two runs of this engine: the order of the
 forward's float atomics (GAP, BatchNorm sums).  In float32 that is 1e-6 on the forward tensors, but a ReLU unit within
 rounding of zero can land on the other side and move one weight gradient by ~1e-3 at this batch size (DESIGN.md section 2,
@@ -55,8 +57,10 @@ def test_fused_launches_equal_separate_launches(tmp_path, dt):
     whether or not the fused launches are on.  (Batch 4 is bimodal: the squeeze-excite BatchNorm over four rows amplifies
     a last-bit difference of a float-atomic sum into percents, in 2 of 5 runs.)"""
     name, B = "c64nb", 16
-    on = _run(tmp_path, "on", {"MVAE_FUSE_PW_CHAIN": "1", "MVAE_FUSE_DW_CONV0": "1"}, name, B, dt)
-    off = _run(tmp_path, "off", {"MVAE_FUSE_PW_CHAIN": "0", "MVAE_FUSE_DW_CONV0": "0"}, name, B, dt)
+    on = _run(tmp_path, "on", {"MVAE_FUSE_PW_CHAIN": "1", "MVAE_FUSE_DW_CONV0": "1", "MVAE_FUSE_DW_CONV0_F32": "1",
+                               "MVAE_SPLIT_DUAL": "1"}, name, B, dt)
+    off = _run(tmp_path, "off", {"MVAE_FUSE_PW_CHAIN": "0", "MVAE_FUSE_DW_CONV0": "0", "MVAE_FUSE_DW_CONV0_F32": "0",
+                                 "MVAE_SPLIT_DUAL": "0"}, name, B, dt)
     diff = on["recon"].astype(np.float64) - off["recon"]
     tol_max, tol_rms = (1e-3, 1e-4) if dt == "f32" else (0.15, 8e-3)
     assert np.abs(diff).max() <= tol_max * 255.0 and np.sqrt((diff ** 2).mean()) <= tol_rms * 255.0
