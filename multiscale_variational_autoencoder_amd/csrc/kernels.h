@@ -296,6 +296,14 @@ bool launch_gemm_dual_split(const float* X, const float* W, const float* aux, co
                             float* Y, float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C,
                             GradSlots sl, int dslots, int64_t dstride, int cap, hipStream_t s);
 const char* gemm_dual_split_kernel(bool gated, int64_t M, int64_t rows_per_image, int C);   // its kernel name, or nullptr
+bool launch_gemm_dual_stats(const float* X, const float* W, const float* aux, const float* gate, unsigned* mask, float* dW,
+                            float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C, GradSlots sl, int dslots,
+                            int64_t dstride, int cap, hipStream_t s);                      // conv2 pair without dt2 (+ mask words)
+// whole MobileNetV3 backward behind the squeeze-excite step in one pass (kernels_fused.hip): dt2 recomputed from dout
+const char* mn_bwd_split_kernel(int B, int H, int W, int C);
+bool launch_mn_bwd_split(const float* dout, const unsigned* mask, const float* t0, const float* w, const float* gate,
+                         const float* dgap, const float* W2, const float* W0, const float* a_in, float* da, float* dW, float* db,
+                         float* dW0, float* db0, GradSlots sl, int B, int H, int W, int C, hipStream_t s);
 // depthwise backward + conv0 backward pair in one pass (kernels_fused.hip): C = 64, W = 32, H even, mask in the LSB of dt2
 const char* dw_bwd_conv0_split_kernel(int B, int H, int W, int C);                         // kernel name, or nullptr
 bool launch_dw_bwd_conv0_split(const float* dt2, const float* t0, const float* w, const float* gate, const float* dgap,

@@ -536,12 +536,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual_s(const float* __restrict_
                                                         float* __restrict__ dW, float* __restrict__ db,
                                                         float* __restrict__ dot_out, int64_t M, int rpi_shift, int nslots,
                                                         int64_t slot_stride, int dslots, int64_t dstride) {
+  // MODE 3 = MODE 1 for the fully fused backward (k_mn_bwd_s, kernels_fused.hip, recomputes Y = dt2 itself): nothing is
+  // stored at Y's 256 bytes per pixel; instead the ReLU mask of aux (t1 > 0) goes out as two 32-bit words per pixel,
+  // mask[pixel*2 + (channel >> 5)] bit (channel & 31), through Y's pointer.
+  constexpr bool GATED = MODE == 1 || MODE == 3;
   constexpr int C = 64, C4 = 16, TR = 64, LD = 4, PL = TR * C * 2;          // PL = bytes of one plane
-  __shared__ __attribute__((aligned(16))) char lds[6 * PL + (MODE == 1 ? TR * C * 4 : 0)];
+  __shared__ __attribute__((aligned(16))) char lds[6 * PL + (GATED ? TR * C * 4 : 0)];
   char* pX = lds;
   char* pA = lds + 3 * PL;
   float* sA = reinterpret_cast<float*>(lds + 6 * PL);                      // MODE 1: raw aux (t1), float32, SWZ layout
-  if (MODE == 1) dot_out += (int64_t)(blockIdx.x % dslots) * dstride;
+  if (GATED) dot_out += (int64_t)(blockIdx.x % dslots) * dstride;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = wave & 1, rw = wave >> 1, n0 = nw * 32;
   const int i = lane & 31, h = lane >> 5;
@@ -578,7 +582,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual_s(const float* __restrict_
     const f32x4* pa = A4 + tile * (TR * C4) + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < LD; ++j) { S.x[j] = px[j * 256]; S.a[j] = pa[j * 256]; }
-    if constexpr (MODE == 1)
+    if constexpr (GATED)
       S.g = reinterpret_cast<const f32x4*>(gate)[(int64_t)((uint32_t)(tile * TR) >> rpi_shift) * C4 + sc4];
   };
   float res[16];
@@ -611,7 +615,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual_s(const float* __restrict_
       *reinterpret_cast<u32x2*>(pX + 2 * PL + off) = p3;
       bs4 += S.x[j];
       f32x4 a = S.a[j];
-      if constexpr (MODE == 1) {
+      if constexpr (GATED) {
         reinterpret_cast<f32x4*>(sA)[SWZ4(r, sc4)] = a;
         a = a * S.g;
       }
@@ -666,7 +670,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual_s(const float* __restrict_
     if (kWgrad) { read_a(1, 1); MVAE_SPLIT6(accw[0], fa[1][0], fb[1]); }
     MVAE_SB();
     if (kWgrad) { MVAE_SPLIT6(accw[1], fa[1][1], fb[1]); }
-    if constexpr (MODE == 1 && MVAE_DUAL_VARIANT != 4) {
+    if constexpr (GATED && MVAE_DUAL_VARIANT != 4) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) av[r] = sA[SWZ1(rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + i)];
     }
@@ -679,12 +683,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm_dual_s(const float* __restrict_
       load_res(next);                                      // ahead of the stores (k_gemm_dual's header comment)
     }
     float* py = Y + ebase;
-    if constexpr (MODE == 1 && MVAE_DUAL_VARIANT != 4) {
+    if constexpr (GATED && MVAE_DUAL_VARIANT != 4) {
       float dsum = 0.f;                                    // the wave's 32 rows lie in one image
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         dsum += acc[r] * av[r];
-        py[((r & 3) + 8 * (r >> 2)) * C] = __uint_as_float((__float_as_uint(acc[r]) & ~1u) | (av[r] > 0.f ? 1u : 0u));
+        if constexpr (MODE == 1) {
+          py[((r & 3) + 8 * (r >> 2)) * C] = __uint_as_float((__float_as_uint(acc[r]) & ~1u) | (av[r] > 0.f ? 1u : 0u));
+        } else {
+          // lanes 0-31: pixel row0 + rc, lanes 32-63: pixel row0 + rc + 4, channels n0 .. n0 + 31 in lane order
+          const unsigned long long bal = __ballot(av[r] > 0.f);
+          if (i == 0) {
+            unsigned* mw = reinterpret_cast<unsigned*>(Y) + (row0 + (r & 3) + 8 * (r >> 2) + 4 * h) * 2 + nw;
+            *mw = h ? (unsigned)(bal >> 32) : (unsigned)bal;
+          }
+        }
       }
       dsum += __shfl_xor(dsum, 32, 64);
       if (h == 0) atomicAdd(dot_out + (int64_t)((uint32_t)row0 >> rpi_shift) * C + n0 + i, dsum);
@@ -749,6 +762,23 @@ bool launch_gemm_dual_split(const float* X, const float* W, const float* aux, co
                      dot_out, M, sh, sl.count(), sl.stride, dslots < 1 ? 1 : dslots, dstride)
   if (m1) MVAE_DS(1); else MVAE_DS(2);
 #undef MVAE_DS
+  return true;
+}
+
+// conv2 pair WITHOUT dt2: dW2, db2, the gate gradient, and the ReLU mask of t1 as bit words (mask[pixel*2 + (c >> 5)]) for
+// k_mn_bwd_s, which recomputes dt2 from dout.  Same coverage as the gated split pair.
+bool launch_gemm_dual_stats(const float* X, const float* W, const float* aux, const float* gate, unsigned* mask, float* dW,
+                            float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C, GradSlots sl, int dslots,
+                            int64_t dstride, int cap, hipStream_t s) {
+  if (!gate || !dot_out || !mask || !gemm_dual_split_kernel(true, M, rows_per_image, C)) return false;
+  const int64_t ntiles = M / 64;
+  static const int cus = [] { const char* e = getenv("MVAE_BIG_CUS"); int n = e ? atoi(e) : 224; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  if (cap <= 0) cap = 2 * cus;                             // two resident blocks per CU (run_gemm_dual, kernels_mfma.hip)
+  const int grid = (int)(ntiles < cap ? ntiles : cap);
+  const int sh = 63 - __builtin_clzll((unsigned long long)rows_per_image);
+  hipLaunchKernelGGL((k_gemm_dual_s<3>), dim3(grid), dim3(256), 0, s, X, W, aux, gate, (const float*)nullptr,
+                     reinterpret_cast<float*>(mask), sl.at(dW), sl.at(db), dot_out, M, sh, sl.count(), sl.stride,
+                     dslots < 1 ? 1 : dslots, dstride);
   return true;
 }
 

@@ -92,9 +92,11 @@ struct Scale {
   hipStream_t wstream = nullptr;
   hipEvent_t ev_prod = nullptr, ev_wjoin = nullptr, ev_buf[4] = {nullptr, nullptr, nullptr, nullptr};
   bool buf_pending[4] = {false, false, false, false};
+  bool w_used = false;                      // launches on wstream since the last join
   int lru[4] = {0, 0, 0, 0}, tick = 0;
   int cmax = 0;
   float *dg, *dgap, *ds1, *dv, *dz, *dmu, *dlv, *dw_part;
+  float* maskbuf = nullptr;                 // float32 scales: ReLU-mask words of t1, two per pixel (k_gemm_dual_s<3> -> k_mn_bwd_s)
   float* d_mid = nullptr;                   // gradient at the encoder output between the two backward phases
 };
 
@@ -135,10 +137,14 @@ struct mvae_handle {
   int64_t off_seed = 0, off_hp = 0;
   // concurrency: scale 0 runs on the caller's stream, every other scale on its own side stream (fork/join with
   // events); each ABI call is captured into a hipGraph per argument signature and replayed.
-  // wgrad_streams: opt-in (MVAE_WGRAD_STREAMS=1).  Correct in eager mode, but the ~450 extra event calls per step
-  // make the host the bottleneck there, and capturing that many cross-stream edges crashes hipGraph (ROCm 7.2).
+  // wgrad_streams (MVAE_WGRAD_STREAMS): 2 (default) = only the k x k convolution weight gradients of scale 0 leave the chain
+  // for its side stream: MFMA-bound kernels (0.27 ms of the headline's scale-0 chain) that move few bytes, next to a chain
+  // that is bound by HBM traffic; a first-level fork the graph capture handles.  1 = every weight gradient of every scale:
+  // correct in eager mode, but the ~450 extra event calls per step make the host the bottleneck there, and a fork from a
+  // stream that itself joined the capture by a fork crashes hipStreamEndCapture (ROCm 7.2), so that mode never captures.
   bool merge_side = false;
-  bool multi_stream = true, use_graphs = true, wgrad_streams = false;
+  bool multi_stream = true, use_graphs = true;
+  int wgrad_streams = 2;
   bool lsb_mask = true;                     // the depthwise backward takes the ReLU mask from the LSB of dt2 (MVAE_LSB_MASK=0: reads t1)
   bool det = false;                         // MVAE_DETERMINISTIC=1 at mvae_create: one slot per block, no split sums (kernels.h)
   int nslots = kGradSlots, stat_slots = kStatSlots;
@@ -441,6 +447,7 @@ int build_plan(mvae_handle* h) {
     sc.dg = as_ptr(b.act("", cm * sc.dg_total)); sc.dgap = as_ptr(b.act("", cm));   // dg: [B, cmax] per slot copy
     sc.ds1 = as_ptr(b.act("", cm)); sc.dv = as_ptr(b.act("", cm));
     sc.dw_part = as_ptr(b.ws_alloc((int64_t)kDwMaxBlocks * 10 * cm));
+    if (!sc.bf) sc.maskbuf = as_ptr(b.act("", 2 * (int64_t)sc.H * sc.W));
     sc.dz = as_ptr(b.act("", sc.z)); sc.dmu = as_ptr(b.act("", sc.z)); sc.dlv = as_ptr(b.act("", sc.z));
     H /= 2; W /= 2;
   }
@@ -515,6 +522,7 @@ void rebase_all(mvae_handle* h) {
     rb(sc.dy);
     for (int k = 0; k < 4; ++k) rb(sc.scratch[k]);
     rb(sc.dw_part);
+    if (sc.maskbuf) rb(sc.maskbuf);
     rb(sc.dg); rb(sc.dgap); rb(sc.ds1); rb(sc.dv); rb(sc.dz); rb(sc.dmu); rb(sc.dlv);
   }
   rb(h->xin);
@@ -531,7 +539,10 @@ void rebase_all(mvae_handle* h) {
 }
 
 // ---- scratch pool (per scale, static order => stable pointers under graph capture) ----------
-bool wgrad_async(mvae_handle* h) { return h->multi_stream && h->wgrad_streams && !profiler().on; }
+bool wgrad_async(mvae_handle* h, const Scale& sc, bool heavy) {
+  if (!h->multi_stream || profiler().on || h->det) return false;
+  return h->wgrad_streams == 1 || (h->wgrad_streams == 2 && heavy && &sc == &h->scales[0]);
+}
 
 // least-recently-released free buffer; if a weight-gradient kernel may still be reading it, the chain waits for it
 float* acquire(mvae_handle* h, Scale& sc, hipStream_t chain) {
@@ -559,8 +570,9 @@ hipEvent_t fresh_event(mvae_handle* h) {
   return h->ev_pool[h->ev_next++];
 }
 // stream for a weight-gradient launch whose inputs the chain has just produced (edge chain -> wstream)
-hipStream_t wgrad_begin(mvae_handle* h, Scale& sc, hipStream_t chain) {
-  if (!wgrad_async(h)) return chain;
+hipStream_t wgrad_begin(mvae_handle* h, Scale& sc, hipStream_t chain, bool heavy = false) {
+  if (!wgrad_async(h, sc, heavy)) return chain;
+  sc.w_used = true;
   hipEvent_t e = fresh_event(h);
   (void)hipEventRecord(e, chain);
   (void)hipStreamWaitEvent(sc.wstream, e, 0);
@@ -568,7 +580,7 @@ hipStream_t wgrad_begin(mvae_handle* h, Scale& sc, hipStream_t chain) {
 }
 // the launches just issued on `w` read pool buffer `p`: it must not be recycled before they finish
 void wgrad_reads(mvae_handle* h, Scale& sc, const float* p, hipStream_t w) {
-  if (!wgrad_async(h)) return;
+  if (w != sc.wstream) return;
   for (int k = 0; k < 4; ++k)
     if (sc.scratch[k] == p) {
       sc.ev_buf[k] = fresh_event(h);
@@ -577,7 +589,8 @@ void wgrad_reads(mvae_handle* h, Scale& sc, const float* p, hipStream_t w) {
     }
 }
 void wgrad_join(mvae_handle* h, Scale& sc, hipStream_t chain) {
-  if (!wgrad_async(h)) return;
+  if (!sc.w_used) return;
+  sc.w_used = false;
   hipEvent_t e = fresh_event(h);
   (void)hipEventRecord(e, sc.wstream);
   (void)hipStreamWaitEvent(chain, e, 0);
@@ -729,8 +742,16 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
     release(sc, dout);
     return bufB;
   }
+  // fully fused form (kernels_fused.hip, k_mn_bwd_s): the conv2 pair leaves no dt2 behind, only the ReLU mask of t1 as bit
+  // words; everything behind the squeeze-excite step is one pass that recomputes dt2 from dout
+  const bool full_fuse = h->lsb_mask && sc.maskbuf && mn_bwd_split_kernel(B, m.H, m.W, c) &&
+                         gemm_dual_split_kernel(true, (int64_t)B * HW, HW, c);
   bool dual2;
-  {
+  if (full_fuse) {
+    ProfScope ps("k_gemm_dual_s<3>", 8.0 * B * HW * c, 4.0 * B * HW * c * c, s);
+    dual2 = launch_gemm_dual_stats(dout, P + m.w2, m.t1, m.g, reinterpret_cast<unsigned*>(sc.maskbuf), G + m.w2, G + m.b2, dg,
+                                   (int64_t)B * HW, HW, c, h->gslots, m.dg_slots, dg_stride, 0, s);
+  } else {
     const char* stag = gemm_dual_split_kernel(true, (int64_t)B * HW, HW, c);
     ProfScope ps(stag ? stag : (c == 64 ? "k_gemm_dual<64, 1>" : "k_gemm_dual<32, 1>"), 12.0 * B * HW * c, 4.0 * B * HW * c * c, s);   // rocprof kernel names
     // dt2 = dout . W2^T ; dW2 += (t1*g)^T dout ; db2 ; dg = sum_hw dt2 * t1     -- one pass over (dout, t1)
@@ -770,6 +791,16 @@ float* mn_backward(mvae_handle* h, Scale& sc, MN& m, const float* x, float* dout
   }
   // through the gate multiply, the global average pool and the depthwise ReLU
   float* bufC = acquire(h, sc, s);
+  if (full_fuse && dual2) {
+    ProfScope ps("k_mn_bwd_s", 16.0 * B * HW * c, (40.0 + 6.0 * c) * B * HW * c, s);
+    if (launch_mn_bwd_split(dout, reinterpret_cast<const unsigned*>(sc.maskbuf), m.t0, P + m.wd, m.g, sc.dgap, P + m.w2,
+                            P + m.w0, x, bufC, G + m.wd, G + m.bd, G + m.w0, G + m.b0, h->gslots, B, m.H, m.W, c, s)) {
+      release(sc, bufB);
+      release(sc, dout);
+      return bufC;
+    }
+    h->kernel_gap = true;                              // unreachable: the coverage tests above are the launchers' own
+  }
   if (dual2 && h->lsb_mask && dw_bwd_conv0_split_kernel(B, m.H, m.W, c)) {
     // ... and conv0's backward pair in the same pass: dt0 is never stored (kernels_fused.hip)
     ProfScope ps("k_dw_bwd_conv0_s", 20.0 * B * HW * c, (40.0 + 4.0 * c) * B * HW * c, s);
@@ -930,7 +961,7 @@ void join_scales(mvae_handle* h, hipStream_t main) {
 int run_captured(mvae_handle* h, const std::string& key, hipStream_t s, const std::function<void(hipStream_t)>& body) {
   // a fork from a stream that itself joined the capture by a fork (the weight-gradient side streams) makes
   // hipStreamEndCapture segfault under ROCm 7.2: that mode never captures, whatever the environment says
-  const bool eligible = h->use_graphs && !h->wgrad_streams && !profiler().on && s != nullptr;
+  const bool eligible = h->use_graphs && h->wgrad_streams != 1 && !profiler().on && s != nullptr;
   if (!eligible) { body(s); return MVAE_OK; }
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
@@ -1123,10 +1154,10 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   set_gauss_constants(gf);
   if (const char* v = getenv("MVAE_GRAPHS")) h->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("MVAE_STREAMS")) h->multi_stream = atoi(v) != 0;
-  if (const char* v = getenv("MVAE_WGRAD_STREAMS")) h->wgrad_streams = atoi(v) != 0;
+  if (const char* v = getenv("MVAE_WGRAD_STREAMS")) h->wgrad_streams = atoi(v);
   if (const char* v = getenv("MVAE_LSB_MASK")) h->lsb_mask = atoi(v) != 0;
   if (const char* v = getenv("MVAE_MERGE_SIDE")) h->merge_side = atoi(v) != 0;   // all scales > 0 on ONE side stream
-  if (h->wgrad_streams) h->use_graphs = false;
+  if (h->wgrad_streams == 1) h->use_graphs = false;
   // scale 0 (on the caller's stream) is the long pole of every step and the other scales only fill the gaps it leaves,
   // so low-priority side streams look natural -- but they buy 0.4 % on the first handle of a process and cost up to 50 %
   // on every later one (measured, tools/chain_only.py: a second handle's side streams then share a hardware queue with
@@ -1144,7 +1175,7 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
     e = hipStreamCreateWithFlags(&sc.wstream, hipStreamNonBlocking);
   }
   // cross-stream edges of one backward pass: pre-created, so that no event is created while a capture is open
-  for (int k = 0; h->wgrad_streams && k < 2048 && e == hipSuccess; ++k) {
+  for (int k = 0; h->wgrad_streams && k < (h->wgrad_streams == 1 ? 2048 : 64) && e == hipSuccess; ++k) {
     hipEvent_t ev = nullptr;
     e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e == hipSuccess) h->ev_pool.push_back(ev);
@@ -1363,7 +1394,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
           need16(h, launch_colstat_opt(0, d, nullptr, 0, 0.f, h->gslots.at(G + blk.cb), h->gslots.count(), h->gslots.stride,
                                        (int64_t)B * g.IH * g.IW, g.CI, s, true));
         } else {
-          hipStream_t w = wgrad_begin(h, sc, s);
+          hipStream_t w = wgrad_begin(h, sc, s, g.KH * g.KW > 1);
           launch_conv_wgrad(d, prev, G + blk.cw, nullptr, g, none, h->gslots, w);
           if (!launch_colstat_opt(0, d, nullptr, 0, 0.f, h->gslots.at(G + blk.cb), h->gslots.count(), h->gslots.stride,
                                   (int64_t)B * g.IH * g.IW, g.CI, w))
@@ -1447,7 +1478,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
         if (sc.bf) {
           need16(h, launch16_wgrad(prev, d, G + blk.cw, G + blk.cb, g, h->gslots, s));
         } else {
-          hipStream_t w = wgrad_begin(h, sc, s);
+          hipStream_t w = wgrad_begin(h, sc, s, g.KH * g.KW > 1);
           launch_conv_wgrad(prev, d, G + blk.cw, G + blk.cb, g, none, h->gslots, w);
           wgrad_reads(h, sc, d, w);
         }
