@@ -281,15 +281,15 @@ static bool split_enabled() {
 }
 
 // =================================================================================================
-// Hardware self-test.  On some MI355X boxes of the development pool (3 of 12 seen, identified by serial number, stable per
-// box) a plain VALU kernel running on another stream WHILE k_conv_taps_s runs came back with wrong results: one register,
-// one 16-lane quarter of a wave, one term of an FMA chain off -- e.g. 16 outputs of the decoder's Dense layer wrong by ~1 %
-// in 5 % of its launches (tools/split_debug2.py).  It needs this kernel's instruction mix (dense bf16 MFMA bursts + LDS +
-// the split's VALU work); with the kernel's global stores removed it still happens, on one stream it does not, with the
-// float32-MFMA kernel it does not, on the other boxes it never does: marginal silicon, not a data race.  A kernel that can
-// expose that must not be the default on such a board: the first bind of a process that wants the split path runs the
-// kernel next to a self-checking VALU kernel for a few milliseconds and keeps the float32-MFMA kernels if a single value
-// differs (mvae_split_conv_status reports which; MVAE_SPLIT_SELFTEST=0 skips the test).
+// Hardware self-test.  While a wave interleaves float32 VALU work with v_mfma_f32_32x32x16_bf16 --
+// which is what every split kernel does -- a v_pk_fma_f32 of ANOTHER wave on the same SIMD now and then returns a wrong
+// value in one 16-lane group (found as 16 wrong outputs of the decoder's Dense layer in a few percent of its launches,
+// tools/split_debug2.py; integer VALU and plain v_fma_f32 victims are not affected, the float32-MFMA convolution as the
+// neighbour does not trigger it, the kernels share no memory).  The library is therefore built without packed float32
+// instructions (_build.py).  The first bind of a process whose plan uses split kernels checks exactly that: the split
+// kernels on one stream, a self-checking VALU kernel as this library compiles it on another -- a single wrong value and
+// the process keeps the float32-MFMA kernels (mvae_split_conv_status) -- and the same check kernel compiled WITH packed
+// float32, whose count of wrong values is reported (mvae_split_conv_erratum; MVAE_SPLIT_SELFTEST=0 skips both).
 // =================================================================================================
 template <int VV>
 __global__ void __launch_bounds__(256) __attribute__((target("packed-fp32-ops"))) k_selftest_victim_v(const float* __restrict__ z, const f32x4* __restrict__ W,

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Locally, after tools/collect_profiles.sh ran through gpurun: copy / summarise what the judge reads into profiles/.
+# (The bench lines profiles/round3_bench_line_*.json come from plain `python bench.py [--workload c256nb]` runs.)
 set -e
 cd "$(dirname "$0")/.."
 O=gpurun_out/r3prof
@@ -25,11 +26,4 @@ for k, v in agg.items():
     out[k] = dict(launches=n[k], mfma_busy_cycles=v['SQ_VALU_MFMA_BUSY_CYCLES'], grbm_gui_active=v.get('GRBM_GUI_ACTIVE', 0),
                   mfma_util=v['SQ_VALU_MFMA_BUSY_CYCLES'] / max(v.get('GRBM_GUI_ACTIVE', 1) * 128, 1))
 json.dump(out, open('profiles/round3_pmc_mfma_c256nb.json', 'w'), indent=1, sort_keys=True)
-for wl in ("c32nb", "c256nb"):
-    try:
-        d = json.loads(open('gpurun_out/bench_line_%s.json' % wl).read().strip().splitlines()[-1])
-        open('profiles/round3_bench_line_%s.json' % wl, 'w').write(json.dumps(d) + "\n")
-        print(wl, d["value"], d["ms_per_step"], d["step_roofline"]["hbm_frac"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["traffic"])
-    except OSError:
-        pass
 PY
