@@ -137,14 +137,15 @@ struct mvae_handle {
   int64_t off_seed = 0, off_hp = 0;
   // concurrency: scale 0 runs on the caller's stream, every other scale on its own side stream (fork/join with
   // events); each ABI call is captured into a hipGraph per argument signature and replayed.
-  // wgrad_streams (MVAE_WGRAD_STREAMS): 2 (default) = only the k x k convolution weight gradients of scale 0 leave the chain
-  // for its side stream: MFMA-bound kernels (0.27 ms of the headline's scale-0 chain) that move few bytes, next to a chain
-  // that is bound by HBM traffic; a first-level fork the graph capture handles.  1 = every weight gradient of every scale:
+  // wgrad_streams (MVAE_WGRAD_STREAMS): 0 (default) = weight gradients stay on their scale's chain.  2 = the k x k
+  // convolution weight gradients of scale 0 leave the chain for its side stream (MFMA-bound kernels, 0.27 ms of the headline's
+  // scale-0 chain, a first-level fork the graph capture handles): measured 5.27 against 5.24 ms -- the step is bound by what it
+  // moves, not by that chain -- so it stays opt-in.  1 = every weight gradient of every scale:
   // correct in eager mode, but the ~450 extra event calls per step make the host the bottleneck there, and a fork from a
   // stream that itself joined the capture by a fork crashes hipStreamEndCapture (ROCm 7.2), so that mode never captures.
   bool merge_side = false;
   bool multi_stream = true, use_graphs = true;
-  int wgrad_streams = 2;
+  int wgrad_streams = 0;
   bool lsb_mask = true;                     // the depthwise backward takes the ReLU mask from the LSB of dt2 (MVAE_LSB_MASK=0: reads t1)
   bool det = false;                         // MVAE_DETERMINISTIC=1 at mvae_create: one slot per block, no split sums (kernels.h)
   int nslots = kGradSlots, stat_slots = kStatSlots;
