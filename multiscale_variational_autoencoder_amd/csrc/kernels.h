@@ -309,6 +309,11 @@ const char* dw_bwd_conv0_split_kernel(int B, int H, int W, int C);              
 bool launch_dw_bwd_conv0_split(const float* dt2, const float* t0, const float* w, const float* gate, const float* dgap,
                                const float* W0, const float* a_in, const float* dout, float* da, float* dW, float* db,
                                float* dW0, float* db0, GradSlots sl, int B, int H, int W, int C, hipStream_t s);
+// conv2 of a block + conv0 and depthwise stage of the next one in one pass (kernels_fused_fwd.hip)
+const char* mn_fwd_chain_split_kernel(int B, int H, int W, int C);
+bool launch_mn_fwd_chain_split(const float* t1, const float* gate, const float* x, const float* W2, const float* b2,
+                               const float* W0n, const float* b0n, const float* wdn, const float* bdn, float* y, float* t0n,
+                               float* t1n, float* gapn, int B, int H, int W, int C, hipStream_t s);
 int split_conv_status();               // 0 switched off (MVAE_SPLIT_CONV=0), 1 in use, 2 disabled by the self-test on this board
 bool launch_conv_taps_split(bool transposed, const float* in, const void* planes, const float* bias, float* out,
                             const ConvGeom& g, hipStream_t s);

@@ -631,8 +631,11 @@ inline void need16(mvae_handle* h, bool ok) { if (!ok) h->kernel_gap = true; }
 // block is 32 wide -- that convolution and the next conv0 then ride along too.  conv0_done: this block's conv0 was
 // computed by the previous block's launch.  Returns 0 = nothing chained, 1 = the next conv0 is done, 2 = the next
 // block's convolution and conv0 are done.
+// 3 = the next block's conv0 AND its depthwise 3x3 + ReLU + GAP are done (k_mn_fwd_chain_s, kernels_fused_fwd.hip).
+// chained_in: what the previous block's call returned.
 int mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipStream_t s, bool bf, MN* chain = nullptr,
-               bool conv0_done = false, Block* chain3 = nullptr, bool chain3_transposed = false) {
+               int chained_in = 0, Block* chain3 = nullptr, bool chain3_transposed = false) {
+  const bool conv0_done = chained_in != 0, dw_done = chained_in == 3;
   const float* P = h->dp;
   float* stats = h->dr + h->P;
   const int c = m.c;
@@ -649,8 +652,8 @@ int mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipS
     }
     if (!tiled0) launch_conv_f(x, P + m.w0, P + m.b0, nullptr, m.t0, g, none, ACT_RELU, s);
   }
-  bool fused_dw;
-  {
+  bool fused_dw = dw_done;
+  if (!dw_done) {
     ProfScope ps(dw_uses_img(false, false, B, m.H, m.W, c) ? "k_dw_fwd_img" : "k_dw_fwd_ring<true>", (bf ? 4.0 : 8.0) * B * m.H * m.W * c,
                  20.0 * B * m.H * m.W * c, s);
     fused_dw = launch_dw_fwd_gap(m.t0, P + m.wd, P + m.bd, m.t1, m.gap, B, m.H, m.W, c, s, bf);
@@ -679,6 +682,13 @@ int mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipS
       return 2;
     need16(h, launch16_pw(false, m.t1, P + m.w2, P + m.b2, m.g, x, m.out, M, HW, c, c, ACT_NONE, s, m.out_f32));
     return 0;
+  }
+  if (chain && chain->c == c && chain->H == m.H && chain->W == m.W && mn_fwd_chain_split_kernel(B, m.H, m.W, c)) {
+    // conv2 of this block, conv0 and the depthwise stage of the next one in one pass (t0' is not read back)
+    ProfScope ps("k_mn_fwd_chain_s", 20.0 * B * m.H * m.W * c, (4.0 * c + 20.0) * B * m.H * m.W * c, s);
+    if (launch_mn_fwd_chain_split(m.t1, m.g, x, P + m.w2, P + m.b2, P + chain->w0, P + chain->b0, P + chain->wd, P + chain->bd,
+                                  m.out, chain->t0, chain->t1, chain->gap, B, m.H, m.W, c, s))
+      return 3;
   }
   if (chain && chain->c == c && chain->H == m.H && chain->W == m.W) {
     ProfScope ps("k_conv2_chain", 16.0 * B * m.H * m.W * c, 4.0 * B * m.H * m.W * c * c, s);
@@ -883,7 +893,7 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
     MN* nextmn = (nb && !nb->has_conv) ? &nb->mn : nullptr;
     Block* next3 = (nb && nb->has_conv && nb->cg.KH * nb->cg.KW == 1 && nb->cg.SH == 1 && nb->cg.SW == 1 &&
                     nb->cg.CO == 64 && nb->cg.CI == 32) ? nb : nullptr;          // convT: CO = its input, CI = its output
-    chained = mn_forward(h, blk.mn, x, B, training, s, sc.bf, nextmn, chained != 0, next3, true);
+    chained = mn_forward(h, blk.mn, x, B, training, s, sc.bf, nextmn, chained, next3, true);
     x = blk.mn.out;
   }
   const int64_t M = (int64_t)B * sc.H * sc.W;
@@ -1278,7 +1288,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
         MN* nextmn = (nb && !nb->has_conv) ? &nb->mn : nullptr;
         Block* next3 = (nb && nb->has_conv && nb->cg.KH * nb->cg.KW == 1 && nb->cg.SH == 1 && nb->cg.SW == 1 &&
                         nb->cg.CI == 64 && nb->cg.CO == 32) ? nb : nullptr;
-        chained = mn_forward(h, blk.mn, x, B, training, ss, sc.bf, nextmn, chained != 0, next3, false);
+        chained = mn_forward(h, blk.mn, x, B, training, ss, sc.bf, nextmn, chained, next3, false);
         x = blk.mn.out;
       }
       bool fused_heads;
