@@ -314,6 +314,9 @@ const char* mn_fwd_chain_split_kernel(int B, int H, int W, int C);
 bool launch_mn_fwd_chain_split(const float* t1, const float* gate, const float* x, const float* W2, const float* b2,
                                const float* W0n, const float* b0n, const float* wdn, const float* bdn, float* y, float* t0n,
                                float* t1n, float* gapn, int B, int H, int W, int C, hipStream_t s);
+bool launch_mn_fwd_first_split(const float* x, const float* W0, const float* b0, const float* wd, const float* bd, float* t0,
+                               float* t1, float* gap, int B, int H, int W, int C, hipStream_t s);   // conv0 + depthwise stage
+bool mn_fwd_first_split_on();
 int split_conv_status();               // 0 switched off (MVAE_SPLIT_CONV=0), 1 in use, 2 disabled by the self-test on this board
 bool launch_conv_taps_split(bool transposed, const float* in, const void* planes, const float* bias, float* out,
                             const ConvGeom& g, hipStream_t s);

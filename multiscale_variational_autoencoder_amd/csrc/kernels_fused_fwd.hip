@@ -26,7 +26,10 @@ constexpr int kFwdPlane = 32 * 128;
 constexpr int kFwdLds = kFwdRing + 12 * kFwdPlane + 2 * 32 * 64 * 4 + 2 * 24 * 64 * 16 + 4 * 256;
 }
 
-template <int W_>
+// FIRST: the block that opens a chain (its input comes from a k x k convolution or conv_base, no conv2 ahead of it): conv0 +
+// depthwise stage only, x -> t0, t1, gap (3 passes instead of 4).  Phase A then splits the INPUT tiles of pair i-1 where
+// the chained form splits the block output, and waves 0-3 have nothing to do in phase B.
+template <int W_, bool FIRST>
 __global__ void __launch_bounds__(512, 1) k_mn_fwd_chain_s(const f32x4* __restrict__ t1, const float* __restrict__ gate,
                                                            const float* __restrict__ x, const float* __restrict__ W2,
                                                            const float* __restrict__ b2, const float* __restrict__ W0n,
@@ -54,7 +57,7 @@ __global__ void __launch_bounds__(512, 1) k_mn_fwd_chain_s(const f32x4* __restri
       const float* Wm = mtx ? W0n : W2;
       unsigned v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = __float_as_uint(Wm[(int64_t)(kq * 16 + 8 * h + j) * C + nt * 32 + i]);
+      for (int j = 0; j < 8; ++j) v[j] = (FIRST && !mtx) ? 0u : __float_as_uint(Wm[(int64_t)(kq * 16 + 8 * h + j) * C + nt * 32 + i]);
       u32x2 a1, a2, a3, b1, b2_, b3;
       split4(u32x4{v[0], v[1], v[2], v[3]}, a1, a2, a3);
       split4(u32x4{v[4], v[5], v[6], v[7]}, b1, b2_, b3);
@@ -64,7 +67,7 @@ __global__ void __launch_bounds__(512, 1) k_mn_fwd_chain_s(const f32x4* __restri
       wf[((nt * 4 + kq) * 3 + 2) * 64 + lane] = u32x4{a3[0], a3[1], b3[0], b3[1]};
     }
   }
-  if (threadIdx.x < 64) { sv[threadIdx.x] = b2[threadIdx.x]; sv[64 + threadIdx.x] = b0n[threadIdx.x]; }
+  if (threadIdx.x < 64) { sv[threadIdx.x] = FIRST ? 0.f : b2[threadIdx.x]; sv[64 + threadIdx.x] = b0n[threadIdx.x]; }
   if (threadIdx.x < NS * 32) {                                         // columns 0 and W + 1 of every slot: always zero
     const int slot = threadIdx.x >> 5, side = (threadIdx.x >> 4) & 1;
     ring[(slot * XSP + (side ? W_ + 1 : 0)) * 16 + c4] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -81,31 +84,43 @@ __global__ void __launch_bounds__(512, 1) k_mn_fwd_chain_s(const f32x4* __restri
   const int HW = H * W_, NT = HW / 32, NP = NT / 2;
   const float* gA_b2 = sv + gnt * 32 + i;                              // bias of the wave's output channel
 
+  // the block's images form one stream of fetches (as in k_dw_bwd_conv0_s): tiles NT, NT + 1 of an image are tiles 0, 1 of
+  // the block's next one, whose gate vector is requested an image ahead
+  f32x4 T1[2];
+  float R[16];
+  f32x4 g_nx = FIRST ? f32x4{1.f, 1.f, 1.f, 1.f} : reinterpret_cast<const f32x4*>(gate)[(int64_t)blockIdx.x * 16 + c4];
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const int64_t ioff = (int64_t)b * HW * 16;                         // float4 offset of the image
-    const int64_t poff = (int64_t)b * HW;                              // pixel offset
-    const f32x4 gq = reinterpret_cast<const f32x4*>(gate)[(int64_t)b * 16 + c4];
-    auto fetch_t1 = [&](int t) { return t1[ioff + (int64_t)(min(t, NT - 1) * 32 + px) * 16 + c4]; };
+    const bool first = b == (int)blockIdx.x;
+    const int bn = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;    // next image of this block (or a harmless refetch)
+    const int64_t ioff = (int64_t)b * HW * 16, ioff_n = (int64_t)bn * HW * 16;   // float4 offsets of the two images
+    const int64_t poff = (int64_t)b * HW, poff_n = (int64_t)bn * HW;   // pixel offsets
+    const f32x4 gq = g_nx;
+    if (!FIRST) g_nx = reinterpret_cast<const f32x4*>(gate)[(int64_t)bn * 16 + c4];
+    auto fetch_t1 = [&](int t) {                                       // t >= NT: tile t - NT of the next image
+      const bool nx = t >= NT;
+      return t1[(nx ? ioff_n : ioff) + (int64_t)(min(nx ? t - NT : t, NT - 1) * 32 + px) * 16 + c4];
+    };
     // residual x of the wave's y tile, accumulator layout (lane = channel, 16 pixel rows): waves 0-3
-    float R[16];
     auto fetch_res = [&](int t) {
-      const float* pr = x + (poff + (int64_t)min(t, NT - 1) * 32 + 4 * h) * C + gnt * 32 + i;
+      const bool nx = t >= NT;
+      const float* pr = x + ((nx ? poff_n : poff) + (int64_t)min(nx ? t - NT : t, NT - 1) * 32 + 4 * h) * C + gnt * 32 + i;
 #pragma unroll
       for (int r = 0; r < 16; ++r) R[r] = pr[((r & 3) + 8 * (r >> 2)) * C];
     };
-    f32x4 T1[2];
     f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                  // previous image's LDS reads are done (and the fragments are written)
-    T1[0] = fetch_t1(0);
-    T1[1] = fetch_t1(1);
-    if (gemm1_wave) fetch_res(gkk);
+    if (first) {                                      // later images: fetched by the previous image's last pass
+      T1[0] = fetch_t1(0);
+      T1[1] = fetch_t1(1);
+      if (!FIRST && gemm1_wave) fetch_res(gkk);
+    }
     if (ry == 0) {                                    // image row -1: zeros
       rbase[(((-1) & (NS - 1)) * XSP + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll 1
-    for (int it = 0; it <= NP + 1; ++it) {
+    for (int it = FIRST ? 1 : 0; it <= NP + 1; ++it) {
       // ---- phase A
-      if (it < NP) {
+      if (!FIRST && it < NP) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           u32x2 p1, p2, p3;
@@ -119,12 +134,13 @@ __global__ void __launch_bounds__(512, 1) k_mn_fwd_chain_s(const f32x4* __restri
       if (it >= 1 && it <= NP) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          const f32x4 yv = reinterpret_cast<const f32x4*>(tY)[(kk * 32 + px) * 16 + c4];
+          const f32x4 yv = FIRST ? T1[kk] : reinterpret_cast<const f32x4*>(tY)[(kk * 32 + px) * 16 + c4];
           u32x2 p1, p2, p3;
           split4(__builtin_bit_cast(u32x4, yv), p1, p2, p3);
           *reinterpret_cast<u32x2*>(tYp + (kk * 3 + 0) * TP + st_off) = p1;
           *reinterpret_cast<u32x2*>(tYp + (kk * 3 + 1) * TP + st_off) = p2;
           *reinterpret_cast<u32x2*>(tYp + (kk * 3 + 2) * TP + st_off) = p3;
+          if (FIRST) T1[kk] = fetch_t1(2 * it + kk);
         }
       }
       __syncthreads();
@@ -133,7 +149,7 @@ __global__ void __launch_bounds__(512, 1) k_mn_fwd_chain_s(const f32x4* __restri
         rbase[((H & (NS - 1)) * XSP + 1) * 16] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       if (gemm1_wave) {
-        if (it < NP) {
+        if (!FIRST && it < NP) {
           const int t = 2 * it + gkk;                                  // the wave's tile
           f32x16 acc;
 #pragma unroll
@@ -238,9 +254,12 @@ const char* mn_fwd_chain_split_kernel(int B, int H, int W, int C) {
   if (C != 64 || (W != 32 && W != 16 && W != 8) || (H * W) % 64 != 0 || H < 4 || B < 1) return nullptr;
   if ((int64_t)B * H * W >= (1LL << 31) / 64) return nullptr;
   static const bool attr =
-      hipFuncSetAttribute((const void*)k_mn_fwd_chain_s<32>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds) == hipSuccess &&
-      hipFuncSetAttribute((const void*)k_mn_fwd_chain_s<16>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds) == hipSuccess &&
-      hipFuncSetAttribute((const void*)k_mn_fwd_chain_s<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds) == hipSuccess;
+      hipFuncSetAttribute((const void*)k_mn_fwd_chain_s<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds) == hipSuccess &&
+      hipFuncSetAttribute((const void*)k_mn_fwd_chain_s<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds) == hipSuccess &&
+      hipFuncSetAttribute((const void*)k_mn_fwd_chain_s<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds) == hipSuccess &&
+      hipFuncSetAttribute((const void*)k_mn_fwd_chain_s<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds) == hipSuccess &&
+      hipFuncSetAttribute((const void*)k_mn_fwd_chain_s<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds) == hipSuccess &&
+      hipFuncSetAttribute((const void*)k_mn_fwd_chain_s<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds) == hipSuccess;
   if (!attr) return nullptr;
   return "k_mn_fwd_chain_s";
 }
@@ -250,10 +269,28 @@ bool launch_mn_fwd_chain_split(const float* t1, const float* gate, const float* 
   if (!mn_fwd_chain_split_kernel(B, H, W, C)) return false;
   static const int cus = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
   const int grid = B < cus ? B : cus;
-#define MVAE_FF(WW)                                                                                                      \
-  hipLaunchKernelGGL(k_mn_fwd_chain_s<WW>, dim3(grid), dim3(512), kFwdLds, s, (const f32x4*)t1, gate, x, W2, b2, W0n, b0n, \
-                     (const f32x4*)wdn, (const f32x4*)bdn, y, t0n, (f32x4*)t1n, (f32x4*)gapn, H, 1.0f / (float)(H * W), B)
-  if (W == 32) MVAE_FF(32); else if (W == 16) MVAE_FF(16); else MVAE_FF(8);
+#define MVAE_FF(WW, FI)                                                                                                  \
+  hipLaunchKernelGGL((k_mn_fwd_chain_s<WW, FI>), dim3(grid), dim3(512), kFwdLds, s, (const f32x4*)t1, gate, x, W2, b2, W0n, \
+                     b0n, (const f32x4*)wdn, (const f32x4*)bdn, y, t0n, (f32x4*)t1n, (f32x4*)gapn, H, 1.0f / (float)(H * W), B)
+  if (W == 32) MVAE_FF(32, false); else if (W == 16) MVAE_FF(16, false); else MVAE_FF(8, false);
+  return true;
+}
+bool mn_fwd_first_split_on() {
+  static const bool on = [] { const char* e = getenv("MVAE_FUSE_MN_FWD"); return e ? atoi(e) != 2 : true; }();   // 2: chained form only
+  return on;
+}
+// the block that opens a chain: conv0 (bias, ReLU) + depthwise 3x3 + ReLU + GAP from the block input, x -> t0, t1, gap
+bool launch_mn_fwd_first_split(const float* x_in, const float* W0, const float* b0, const float* wd, const float* bd, float* t0_out,
+                               float* t1_out, float* gap_out, int B, int H, int W, int C, hipStream_t s) {
+  if (!mn_fwd_first_split_on() || !mn_fwd_chain_split_kernel(B, H, W, C)) return false;
+  static const int cus = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  const int grid = B < cus ? B : cus;
+  const float* gate = nullptr; const float* W2 = nullptr; const float* b2 = nullptr; float* y = nullptr;
+  const float* x = nullptr;
+  const float* W0n = W0; const float* b0n = b0; const float* wdn = wd; const float* bdn = bd;
+  float* t0n = t0_out; float* t1n = t1_out; float* gapn = gap_out;
+  const float* t1 = x_in;                                              // the kernel's thread-layout input stream
+  if (W == 32) MVAE_FF(32, true); else if (W == 16) MVAE_FF(16, true); else MVAE_FF(8, true);
 #undef MVAE_FF
   return true;
 }

@@ -635,7 +635,8 @@ inline void need16(mvae_handle* h, bool ok) { if (!ok) h->kernel_gap = true; }
 // chained_in: what the previous block's call returned.
 int mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipStream_t s, bool bf, MN* chain = nullptr,
                int chained_in = 0, Block* chain3 = nullptr, bool chain3_transposed = false) {
-  const bool conv0_done = chained_in != 0, dw_done = chained_in == 3;
+  const bool conv0_done = chained_in != 0;
+  bool dw_first = false;                              // this call's FIRST-form launch did conv0 and the depthwise stage
   const float* P = h->dp;
   float* stats = h->dr + h->P;
   const int c = m.c;
@@ -644,6 +645,12 @@ int mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipS
   PreOp none{nullptr, nullptr, nullptr};
   if (bf) {
     if (!conv0_done) need16(h, launch16_pw(false, x, P + m.w0, P + m.b0, nullptr, nullptr, m.t0, M, HW, c, c, ACT_RELU, s));
+  } else if (!conv0_done && mn_fwd_first_split_on() && mn_fwd_chain_split_kernel(B, m.H, m.W, c) && [&] {
+               // conv0 and the depthwise stage in one pass: x -> t0, t1, gap (kernels_fused_fwd.hip, FIRST form)
+               ProfScope ps("k_mn_fwd_first_s", 12.0 * B * m.H * m.W * c, (2.0 * c + 20.0) * B * m.H * m.W * c, s);
+               return launch_mn_fwd_first_split(x, P + m.w0, P + m.b0, P + m.wd, P + m.bd, m.t0, m.t1, m.gap, B, m.H, m.W, c, s);
+             }()) {
+    dw_first = true;
   } else if (!conv0_done) {
     bool tiled0;
     {
@@ -652,6 +659,7 @@ int mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipS
     }
     if (!tiled0) launch_conv_f(x, P + m.w0, P + m.b0, nullptr, m.t0, g, none, ACT_RELU, s);
   }
+  const bool dw_done = chained_in == 3 || dw_first;
   bool fused_dw = dw_done;
   if (!dw_done) {
     ProfScope ps(dw_uses_img(false, false, B, m.H, m.W, c) ? "k_dw_fwd_img" : "k_dw_fwd_ring<true>", (bf ? 4.0 : 8.0) * B * m.H * m.W * c,
