@@ -266,8 +266,10 @@ def secondary_workload(wname, local, torch, dist, lr, rf, kf, clip, profile=True
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)        # >= 50 timed steps unless the caller says otherwise
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)       # >= 50 timed steps unless the caller says otherwise
+    # 100 untimed steps (0.5 s): the first process on a fresh box runs its first few hundred milliseconds 1.5 % slower
+    # (tools/cold_warm.sh: 5.14 / 5.16 ms for the first two 60-step processes, 5.06 - 5.08 afterwards and with --warmup 300)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="c32nb", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"], help="activation storage (default: the workload's)")
