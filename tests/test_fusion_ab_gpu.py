@@ -1,7 +1,8 @@
 """GPU: the fused launches against the launches they replace.  The switches are read once per process
 (MVAE_FUSE_PW_CHAIN: conv2 + next block's conv0 in one launch, float32 and bf16; MVAE_FUSE_DW_CONV0: depthwise
 backward + conv0's backward pair, bf16; MVAE_FUSE_DW_CONV0_F32: the same pass in float32 on split-bf16 products, 32- and
-16-wide maps; MVAE_FUSE_MN_BWD: that pass with dt2 recomputed inside it (off by default: slower); MVAE_SPLIT_DUAL: the 1x1 backward pairs on split-bf16 products instead of float32 MFMAs), so each variant
+16-wide maps; MVAE_FUSE_MN_BWD: that pass with dt2 recomputed inside it (off by default: slower); MVAE_FUSE_MN_FWD: conv2 + next
+conv0 + next depthwise stage in one forward pass; MVAE_SPLIT_DUAL: the 1x1 backward pairs on split-bf16 products instead of float32 MFMAs), so each variant
 runs in a subprocess.  Fused and separate launches round at
 the same points; what differs between two runs is what differs between ANY two runs of this engine: the order of the
 forward's float atomics (GAP, BatchNorm sums).  In float32 that is 1e-6 on the forward tensors, but a ReLU unit within
@@ -58,9 +59,9 @@ def test_fused_launches_equal_separate_launches(tmp_path, dt):
     a last-bit difference of a float-atomic sum into percents, in 2 of 5 runs.)"""
     name, B = "c64nb", 16
     on = _run(tmp_path, "on", {"MVAE_FUSE_PW_CHAIN": "1", "MVAE_FUSE_DW_CONV0": "1", "MVAE_FUSE_DW_CONV0_F32": "1",
-                               "MVAE_SPLIT_DUAL": "1", "MVAE_FUSE_MN_BWD": "1"}, name, B, dt)
+                               "MVAE_SPLIT_DUAL": "1", "MVAE_FUSE_MN_BWD": "1", "MVAE_FUSE_MN_FWD": "1"}, name, B, dt)
     off = _run(tmp_path, "off", {"MVAE_FUSE_PW_CHAIN": "0", "MVAE_FUSE_DW_CONV0": "0", "MVAE_FUSE_DW_CONV0_F32": "0",
-                                 "MVAE_SPLIT_DUAL": "0", "MVAE_FUSE_MN_BWD": "0"}, name, B, dt)
+                                 "MVAE_SPLIT_DUAL": "0", "MVAE_FUSE_MN_BWD": "0", "MVAE_FUSE_MN_FWD": "0"}, name, B, dt)
     diff = on["recon"].astype(np.float64) - off["recon"]
     tol_max, tol_rms = (1e-3, 1e-4) if dt == "f32" else (0.15, 8e-3)
     assert np.abs(diff).max() <= tol_max * 255.0 and np.sqrt((diff ** 2).mean()) <= tol_rms * 255.0
