@@ -316,7 +316,12 @@ bool launch_dw_bwd_conv0_split(const float* dt2, const float* t0, const float* w
       hipFuncSetAttribute((const void*)k_dw_bwd_conv0_s<16>, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds) == hipSuccess &&
       hipFuncSetAttribute((const void*)k_dw_bwd_conv0_s<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds) == hipSuccess;
   if (!attr) return false;
-  static const int cus = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  static const int cus32 = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  static const int cus16 = [] { const char* e = getenv("MVAE_FUSED_CUS16"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  // 8-wide maps on half the CUs: these launches are latency-bound (four images per block cost little) and a block of this
+  // kernel has its CU to itself, so the other half of the chip stays open to the other scales' streams (4.98 -> 4.94 ms)
+  static const int cus8 = [] { const char* e = getenv("MVAE_FUSED_CUS8"); int n = e ? atoi(e) : 128; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  const int cus = W == 32 ? cus32 : (W == 16 ? cus16 : cus8);
   int grid = B < cus ? B : cus;
   if (det_mode() && grid > kDetSlots) grid = kDetSlots;
 #define MVAE_FB(WW)                                                                                                      \
@@ -661,7 +666,12 @@ bool launch_mn_bwd_split(const float* dout, const unsigned* mask, const float* t
                          const float* dgap, const float* W2, const float* W0, const float* a_in, float* da, float* dW, float* db,
                          float* dW0, float* db0, GradSlots sl, int B, int H, int W, int C, hipStream_t s) {
   if (!mn_bwd_split_kernel(B, H, W, C)) return false;
-  static const int cus = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  static const int cus32 = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  static const int cus16 = [] { const char* e = getenv("MVAE_FUSED_CUS16"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  // 8-wide maps on half the CUs: these launches are latency-bound (four images per block cost little) and a block of this
+  // kernel has its CU to itself, so the other half of the chip stays open to the other scales' streams (4.98 -> 4.94 ms)
+  static const int cus8 = [] { const char* e = getenv("MVAE_FUSED_CUS8"); int n = e ? atoi(e) : 128; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  const int cus = W == 32 ? cus32 : (W == 16 ? cus16 : cus8);
   const int grid = B < cus ? B : cus;
 #define MVAE_MB(WW)                                                                                                    \
   hipLaunchKernelGGL(k_mn_bwd_s<WW>, dim3(grid), dim3(512), kMnLds, s, (const f32x4*)dout, mask, (const f32x4*)t0,     \

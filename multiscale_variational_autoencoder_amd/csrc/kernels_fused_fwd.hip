@@ -267,7 +267,12 @@ bool launch_mn_fwd_chain_split(const float* t1, const float* gate, const float* 
                                const float* W0n, const float* b0n, const float* wdn, const float* bdn, float* y, float* t0n,
                                float* t1n, float* gapn, int B, int H, int W, int C, hipStream_t s) {
   if (!mn_fwd_chain_split_kernel(B, H, W, C)) return false;
-  static const int cus = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  static const int cus32 = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  static const int cus16 = [] { const char* e = getenv("MVAE_FUSED_CUS16"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  // 8-wide maps on half the CUs: these launches are latency-bound (four images per block cost little) and a block of this
+  // kernel has its CU to itself, so the other half of the chip stays open to the other scales' streams (4.98 -> 4.94 ms)
+  static const int cus8 = [] { const char* e = getenv("MVAE_FUSED_CUS8"); int n = e ? atoi(e) : 128; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  const int cus = W == 32 ? cus32 : (W == 16 ? cus16 : cus8);
   const int grid = B < cus ? B : cus;
 #define MVAE_FF(WW, FI)                                                                                                  \
   hipLaunchKernelGGL((k_mn_fwd_chain_s<WW, FI>), dim3(grid), dim3(512), kFwdLds, s, (const f32x4*)t1, gate, x, W2, b2, W0n, \
@@ -283,7 +288,12 @@ bool mn_fwd_first_split_on() {
 bool launch_mn_fwd_first_split(const float* x_in, const float* W0, const float* b0, const float* wd, const float* bd, float* t0_out,
                                float* t1_out, float* gap_out, int B, int H, int W, int C, hipStream_t s) {
   if (!mn_fwd_first_split_on() || !mn_fwd_chain_split_kernel(B, H, W, C)) return false;
-  static const int cus = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  static const int cus32 = [] { const char* e = getenv("MVAE_FUSED_CUS"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  static const int cus16 = [] { const char* e = getenv("MVAE_FUSED_CUS16"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  // 8-wide maps on half the CUs: these launches are latency-bound (four images per block cost little) and a block of this
+  // kernel has its CU to itself, so the other half of the chip stays open to the other scales' streams (4.98 -> 4.94 ms)
+  static const int cus8 = [] { const char* e = getenv("MVAE_FUSED_CUS8"); int n = e ? atoi(e) : 128; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
+  const int cus = W == 32 ? cus32 : (W == 16 ? cus16 : cus8);
   const int grid = B < cus ? B : cus;
   const float* gate = nullptr; const float* W2 = nullptr; const float* b2 = nullptr; float* y = nullptr;
   const float* x = nullptr;
