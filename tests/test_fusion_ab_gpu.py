@@ -48,8 +48,8 @@ def _run(tmp_path, tag, env, name, B, dt):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
-def test_fused_launches_equal_separate_launches(tmp_path, dt):
+@pytest.mark.parametrize("dt,name,B", [("f32", "c64nb", 16), ("bf16", "c64nb", 16), ("f32", "c32nb", 300)])
+def test_fused_launches_equal_separate_launches(tmp_path, dt, name, B):
     """c64nb, batch 16: 64 / 32 / 16 wide scales (halo and no-halo strips of the fused depthwise kernel, the chained and
     the separate conv2 / conv0 / 1x1 / transposed-convolution launches).  The bars are the measured run-to-run levels of
     ONE build (tools/ab_noise.py, five runs, every pair): float32 pairs agree to 2e-7 (median per-tensor gradient
@@ -57,7 +57,8 @@ def test_fused_launches_equal_separate_launches(tmp_path, dt):
     median, 1-1.7e-2 at the 90th percentile, 0.15-0.34 on the worst tensor and 0.4-0.8 (of 255) RMS on the reconstruction
     whether or not the fused launches are on.  (Batch 4 is bimodal: the squeeze-excite BatchNorm over four rows amplifies
     a last-bit difference of a float-atomic sum into percents, in 2 of 5 runs.)"""
-    name, B = "c64nb", 16
+    # (c32nb at batch 300: 32 / 16 / 8 wide maps, and more images than the 256 blocks of the one-block-per-CU fused kernels:
+    # 44 blocks walk two images -- the fetch stream that continues into the next image -- the others one)
     on = _run(tmp_path, "on", {"MVAE_FUSE_PW_CHAIN": "1", "MVAE_FUSE_DW_CONV0": "1", "MVAE_FUSE_DW_CONV0_F32": "1",
                                "MVAE_SPLIT_DUAL": "1", "MVAE_FUSE_MN_BWD": "1", "MVAE_FUSE_MN_FWD": "1"}, name, B, dt)
     off = _run(tmp_path, "off", {"MVAE_FUSE_PW_CHAIN": "0", "MVAE_FUSE_DW_CONV0": "0", "MVAE_FUSE_DW_CONV0_F32": "0",
@@ -77,7 +78,7 @@ def test_fused_launches_equal_separate_launches(tmp_path, dt):
         if not (k.endswith(".b") or b.ndim == 1):
             worst = max(worst, (k, err), key=lambda kv: kv[1])
     med, p90 = float(np.median(errs)), float(np.percentile(errs, 90))
-    with open(os.path.join(ROOT, "gpurun_out", "fusion_ab_%s.json" % dt), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "fusion_ab_%s_%s_%d.json" % (dt, name, B)), "w") as f:
         json.dump({"worst_weight": worst, "median": med, "p90": p90}, f)
     if dt == "f32":
         assert med <= 1e-3 and p90 <= 5e-3 and worst[1] <= 2e-2, (med, p90, worst)
