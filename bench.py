@@ -313,6 +313,8 @@ def main():
     from multiscale_variational_autoencoder_amd.engine import Engine
     from multiscale_variational_autoencoder_amd.initializers import init_params
     from multiscale_variational_autoencoder_amd import _abi
+    if _abi.load_library().mvae_debug_build() != 0:
+        raise SystemExit("bench.py refuses to measure a MVAE_DEBUG_BUILD=1 library: rebuild without it")
     w = WORKLOADS[args.workload]
     B = args.batch or w["batch"]
     act = args.dtype or w.get("dtype", "f32")

@@ -4,7 +4,7 @@ import os
 
 from ._build import LIB_PATH
 
-MVAE_ABI_VERSION = 3
+MVAE_ABI_VERSION = 4
 MVAE_MAX_LEVELS = 16
 MVAE_MAX_BLOCKS = 16
 MVAE_NAME_CAP = 96
@@ -50,6 +50,7 @@ SYMBOLS = {
     "mvae_deterministic": (C.c_int, [_H]),
     "mvae_split_conv_status": (C.c_int, []),
     "mvae_split_conv_erratum": (C.c_int, []),
+    "mvae_fused_launch_stats": (C.c_int, [C.POINTER(C.c_int32)] * 3),
     "mvae_create": (C.c_int, [C.POINTER(MvaeConfig), C.POINTER(_H)]),
     "mvae_destroy": (None, [_H]),
     "mvae_last_error": (C.c_char_p, [_H]),

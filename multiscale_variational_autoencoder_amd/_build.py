@@ -17,6 +17,22 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libmvae_hip.so cannot be built")
 
 
+STAMP_PATH = os.path.join(CSRC, ".build_flags")
+
+
+def _flag_set():
+    """The environment switches that change the generated code: a library built under one set must not survive as another."""
+    return "packed_f32=%s debug=%s" % (os.environ.get("MVAE_PACKED_F32", "") == "1", os.environ.get("MVAE_DEBUG_BUILD", "") == "1")
+
+
+def _flags_changed():
+    try:
+        return open(STAMP_PATH).read().strip() != _flag_set()
+    except OSError:
+        # no stamp: a prebuilt library that travelled without it (the GPU box) counts as built with the default flags
+        return os.path.exists(LIB_PATH) and _flag_set() != "packed_f32=False debug=False"
+
+
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -27,10 +43,12 @@ def _stale():
 
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -O3 -shared -fPIC over csrc/*.hip + runtime.cpp -> libmvae_hip.so."""
+    if not force and _flags_changed():
+        force = True
     if not force and not _stale():
         return LIB_PATH
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    objs = []
+    objs, jobs = [], []
     for src in srcs:
         obj = os.path.splitext(src)[0] + ".o"
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
@@ -44,14 +62,25 @@ def build(force=False, verbose=False):
                 cmd[1:1] = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Wno-unknown-attributes"]
             if os.environ.get("MVAE_DEBUG_BUILD", "") == "1":     # timing-diagnostic switches (runtime.cpp); never the default
                 cmd.insert(1, "-DMVAE_DEBUG_BUILD")
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            jobs.append(cmd)
         objs.append(obj)
+    if jobs:
+        # one hipcc per translation unit, a few at a time (a unit peaks at ~2 GB; MVAE_BUILD_JOBS overrides)
+        from concurrent.futures import ThreadPoolExecutor
+        nj = max(1, int(os.environ.get("MVAE_BUILD_JOBS", "0")) or min(6, os.cpu_count() or 1))
+
+        def _one(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        with ThreadPoolExecutor(nj) as ex:
+            list(ex.map(_one, jobs))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    with open(STAMP_PATH, "w") as f:
+        f.write(_flag_set() + "\n")
     return LIB_PATH
 
 
@@ -59,8 +88,9 @@ def build_tools(verbose=False):
     """tools/bf16_unit.bin: every bf16 MFMA kernel alone against a double-precision reference (tests/test_bf16_kernels_gpu.py
     runs it on the GPU box; built here because the box has no reason to have a compiler warmed up)."""
     root = os.path.dirname(HERE)
-    for name in ("dual_probe.cpp",):                       # timing probes linked against the same objects (not run by tests)
-        _build_tool(os.path.join(root, "tools", name), verbose)
+    if os.environ.get("MVAE_BUILD_PROBES", "") == "1":     # timing probes linked against the same objects (not run by tests)
+        for name in ("dual_probe.cpp",):
+            _build_tool(os.path.join(root, "tools", name), verbose)
     return _build_tool(os.path.join(root, "tools", "bf16_unit.hip"), verbose)
 
 

@@ -15,6 +15,14 @@ static bool g_det_mode = false;
 bool det_mode() { return g_det_mode; }
 void set_det_mode(bool on) { g_det_mode = on; }
 
+static int g_fused_stats[3] = {0, 0, 0};
+void fused_launch_note(bool fwd, int B, int grid) {
+  ++g_fused_stats[fwd ? 0 : 1];
+  const int ipb = (B + grid - 1) / grid;
+  if (ipb > g_fused_stats[2]) g_fused_stats[2] = ipb;
+}
+void fused_launch_stats(int out[3]) { for (int i = 0; i < 3; ++i) out[i] = g_fused_stats[i]; }
+
 static inline double f4(double n) { return 4.0 * n; }
 // tag with the row count (log2 bucket) so the profile separates the big launches from the launch-bound ones
 static const char* tagm(const char* base, double rows) {

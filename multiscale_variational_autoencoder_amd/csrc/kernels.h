@@ -317,6 +317,10 @@ bool launch_mn_fwd_chain_split(const float* t1, const float* gate, const float* 
 bool launch_mn_fwd_first_split(const float* x, const float* W0, const float* b0, const float* wd, const float* bd, float* t0,
                                float* t1, float* gap, int B, int H, int W, int C, hipStream_t s);   // conv0 + depthwise stage
 bool mn_fwd_first_split_on();
+// process-wide launch geometry of the image-resident fused kernels (diagnostic: tests assert that a case really put
+// several images on a block): launches of the forward / backward kernels, largest ceil(B / grid) seen
+void fused_launch_note(bool fwd, int B, int grid);
+void fused_launch_stats(int out[3]);
 int split_conv_status();               // 0 switched off (MVAE_SPLIT_CONV=0), 1 in use, 2 disabled by the self-test on this board
 bool launch_conv_taps_split(bool transposed, const float* in, const void* planes, const float* bias, float* out,
                             const ConvGeom& g, hipStream_t s);

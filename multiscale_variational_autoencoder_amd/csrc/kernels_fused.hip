@@ -324,6 +324,7 @@ bool launch_dw_bwd_conv0_split(const float* dt2, const float* t0, const float* w
   const int cus = W == 32 ? cus32 : (W == 16 ? cus16 : cus8);
   int grid = B < cus ? B : cus;
   if (det_mode() && grid > kDetSlots) grid = kDetSlots;
+  fused_launch_note(false, B, grid);
 #define MVAE_FB(WW)                                                                                                      \
   hipLaunchKernelGGL(k_dw_bwd_conv0_s<WW>, dim3(grid), dim3(512), kFusedLds, s, (const f32x4*)dt2, (const f32x4*)t0,    \
                      (const f32x4*)w, (const f32x4*)gate, (const f32x4*)dgap, W0, (const f32x4*)a_in, dout, da, sl.at(dW), \

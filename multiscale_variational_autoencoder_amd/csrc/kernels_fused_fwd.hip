@@ -274,6 +274,7 @@ bool launch_mn_fwd_chain_split(const float* t1, const float* gate, const float* 
   static const int cus8 = [] { const char* e = getenv("MVAE_FUSED_CUS8"); int n = e ? atoi(e) : 128; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
   const int cus = W == 32 ? cus32 : (W == 16 ? cus16 : cus8);
   const int grid = B < cus ? B : cus;
+  fused_launch_note(true, B, grid);
 #define MVAE_FF(WW, FI)                                                                                                  \
   hipLaunchKernelGGL((k_mn_fwd_chain_s<WW, FI>), dim3(grid), dim3(512), kFwdLds, s, (const f32x4*)t1, gate, x, W2, b2, W0n, \
                      b0n, (const f32x4*)wdn, (const f32x4*)bdn, y, t0n, (f32x4*)t1n, (f32x4*)gapn, H, 1.0f / (float)(H * W), B)
@@ -295,6 +296,7 @@ bool launch_mn_fwd_first_split(const float* x_in, const float* W0, const float* 
   static const int cus8 = [] { const char* e = getenv("MVAE_FUSED_CUS8"); int n = e ? atoi(e) : 128; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
   const int cus = W == 32 ? cus32 : (W == 16 ? cus16 : cus8);
   const int grid = B < cus ? B : cus;
+  fused_launch_note(true, B, grid);
   const float* gate = nullptr; const float* W2 = nullptr; const float* b2 = nullptr; float* y = nullptr;
   const float* x = nullptr;
   const float* W0n = W0; const float* b0n = b0; const float* wdn = wd; const float* bdn = bd;

@@ -1036,6 +1036,14 @@ int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
 int mvae_deterministic(const mvae_handle* h) { return h ? (h->det ? 1 : 0) : MVAE_E_INVALID; }
 int mvae_split_conv_status(void) { return split_conv_status(); }
 int mvae_split_conv_erratum(void) { return split_conv_erratum_count(); }
+int mvae_fused_launch_stats(int32_t* fwd, int32_t* bwd, int32_t* max_images_per_block) {
+  int v[3];
+  fused_launch_stats(v);
+  if (fwd) *fwd = v[0];
+  if (bwd) *bwd = v[1];
+  if (max_images_per_block) *max_images_per_block = v[2];
+  return MVAE_OK;
+}
 
 int mvae_debug_build(void) {
 #ifdef MVAE_DEBUG_BUILD

@@ -220,6 +220,12 @@ class Engine:
         self._check(self.lib.mvae_graph_stats(self.h, C.byref(cap), C.byref(eager)))
         return cap.value, eager.value
 
+    def fused_launch_stats(self):
+        """Process-wide launch geometry of the image-resident fused kernels (mvae_fused_launch_stats)."""
+        v = [C.c_int32(0) for _ in range(3)]
+        self._check(self.lib.mvae_fused_launch_stats(*[C.byref(x) for x in v]))
+        return {"fwd": v[0].value, "bwd": v[1].value, "max_images_per_block": v[2].value}
+
     def dp_overlap_active(self):
         """Opt-in (MVAE_DP_OVERLAP=1): split the gradient exchange in two messages, the leading Dense-weight region of the
         arena (137 of 144 MB for the 256x256 configurations) travelling while the encoder half of the backward pass still

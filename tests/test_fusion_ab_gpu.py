@@ -48,8 +48,9 @@ def _run(tmp_path, tag, env, name, B, dt):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("dt,name,B", [("f32", "c64nb", 16), ("bf16", "c64nb", 16), ("f32", "c32nb", 300)])
-def test_fused_launches_equal_separate_launches(tmp_path, dt, name, B):
+@pytest.mark.parametrize("dt,name,B,mn_bwd", [("f32", "c64nb", 16, "0"), ("bf16", "c64nb", 16, "0"), ("f32", "c32nb", 300, "0"),
+                                               ("f32", "c32nb", 300, "1")])
+def test_fused_launches_equal_separate_launches(tmp_path, dt, name, B, mn_bwd):
     """c64nb, batch 16: 64 / 32 / 16 wide scales (halo and no-halo strips of the fused depthwise kernel, the chained and
     the separate conv2 / conv0 / 1x1 / transposed-convolution launches).  The bars are the measured run-to-run levels of
     ONE build (tools/ab_noise.py, five runs, every pair): float32 pairs agree to 2e-7 (median per-tensor gradient
@@ -58,9 +59,12 @@ def test_fused_launches_equal_separate_launches(tmp_path, dt, name, B):
     whether or not the fused launches are on.  (Batch 4 is bimodal: the squeeze-excite BatchNorm over four rows amplifies
     a last-bit difference of a float-atomic sum into percents, in 2 of 5 runs.)"""
     # (c32nb at batch 300: 32 / 16 / 8 wide maps, and more images than the 256 blocks of the one-block-per-CU fused kernels:
-    # 44 blocks walk two images -- the fetch stream that continues into the next image -- the others one)
+    # 44 blocks walk two images -- the fetch stream that continues into the next image -- the others one.
+    # mn_bwd "0" is the shipped default: the backward runs k_dw_bwd_conv0_s, the headline's dominant kernel; "1" replaces it
+    # by k_gemm_dual_s<3> + k_mn_bwd_s (dt2 recomputed in the pass; off by default, kept under test as a separate case).
+    # The multi-image path is compared with the ORACLE in tests/test_parity_gpu.py::test_multi_image_blocks_parity.)
     on = _run(tmp_path, "on", {"MVAE_FUSE_PW_CHAIN": "1", "MVAE_FUSE_DW_CONV0": "1", "MVAE_FUSE_DW_CONV0_F32": "1",
-                               "MVAE_SPLIT_DUAL": "1", "MVAE_FUSE_MN_BWD": "1", "MVAE_FUSE_MN_FWD": "1"}, name, B, dt)
+                               "MVAE_SPLIT_DUAL": "1", "MVAE_FUSE_MN_BWD": mn_bwd, "MVAE_FUSE_MN_FWD": "1"}, name, B, dt)
     off = _run(tmp_path, "off", {"MVAE_FUSE_PW_CHAIN": "0", "MVAE_FUSE_DW_CONV0": "0", "MVAE_FUSE_DW_CONV0_F32": "0",
                                  "MVAE_SPLIT_DUAL": "0", "MVAE_FUSE_MN_BWD": "0", "MVAE_FUSE_MN_FWD": "0"}, name, B, dt)
     diff = on["recon"].astype(np.float64) - off["recon"]
@@ -78,7 +82,7 @@ def test_fused_launches_equal_separate_launches(tmp_path, dt, name, B):
         if not (k.endswith(".b") or b.ndim == 1):
             worst = max(worst, (k, err), key=lambda kv: kv[1])
     med, p90 = float(np.median(errs)), float(np.percentile(errs, 90))
-    with open(os.path.join(ROOT, "gpurun_out", "fusion_ab_%s_%s_%d.json" % (dt, name, B)), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "fusion_ab_%s_%s_%d_mnbwd%s.json" % (dt, name, B, mn_bwd)), "w") as f:
         json.dump({"worst_weight": worst, "median": med, "p90": p90}, f)
     if dt == "f32":
         assert med <= 1e-3 and p90 <= 5e-3 and worst[1] <= 2e-2, (med, p90, worst)

@@ -58,15 +58,18 @@ def _dump(name, report):
         json.dump(report, f, indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("name,B", [("tiny", 4), ("odd", 3), ("c32def", 4), ("main", 4), ("c32nb", 8), ("c64nb", 2), ("nbodd", 3), ("c96nb", 3)])
-def test_forward_backward_parity(name, B):
+def parity_case(name, B, tag=None, env_check=None):
+    """One forward + backward of config `name` at batch B on the device against the oracle: every saved tensor, the loss
+    terms, the reconstruction, every gradient tensor, the kink report.  Also the body of the subprocess cases below
+    (`python -m tests.test_parity_gpu NAME B TAG`), which run it under launch-geometry switches that are read once per process."""
     io, oc, orc, res, G, inter, eng, out = _run_pair(name, B)
+    if env_check:
+        env_check(eng)
     rep = {}
     # ---- saved intermediates, layer by layer (first failing layer localises a kernel bug)
     for k, v in inter.items():
-        nm = k[:-4] if k.endswith(".out") and False else k
         try:
-            t = eng.tensor(nm, B).cpu().numpy()
+            t = eng.tensor(k, B).cpu().numpy()
         except KeyError:
             continue
         ref = v.detach().numpy()
@@ -93,7 +96,7 @@ def test_forward_backward_parity(name, B):
     m = eng.metrics()
     rep["metrics/r"] = abs(m["vae_r_loss"] - res["r"].mean()) / abs(res["r"].mean())
     rep["metrics/kl"] = abs(m["vae_kl_loss"] - res["kl"].mean()) / abs(res["kl"].mean())
-    _dump(name, rep)
+    _dump(tag or name, rep)
     bad_fwd = {k: v for k, v in rep.items() if k.startswith("fwd/") and v > 1e-4}
     assert not bad_fwd, bad_fwd
     assert rep["recon_abs"] <= TOL_RECON_ABS, rep["recon_abs"]
@@ -101,7 +104,7 @@ def test_forward_backward_parity(name, B):
         assert rep[k] <= TOL_ELBO, (k, rep[k])
     kr = orc.kink_report()
     rep["kink/units"], rep["kink/flips"], rep["kink/max_abs_at_flip"] = kr["units"], kr["flips"], kr["max_abs_at_flip"]
-    _dump(name, rep)
+    _dump(tag or name, rep)
     check_kink_report(kr)
     zero = structurally_zero(G)
     # the structurally-zero tensors (biases feeding BatchNorm) hold pure summation noise, which grows with the number of
@@ -110,6 +113,59 @@ def test_forward_backward_parity(name, B):
     tol_zero = TOL_GRAD_ZERO * (2 if rows >= 16384 else 1)
     bad = {k: v for k, v in gerr.items() if v > (tol_zero if k in zero else TOL_GRAD)}
     assert not bad, (worst, len(bad), dict(list(bad.items())[:12]))
+    return rep
+
+
+@pytest.mark.parametrize("name,B", [("tiny", 4), ("odd", 3), ("c32def", 4), ("main", 4), ("c32nb", 8), ("c64nb", 2), ("nbodd", 3), ("c96nb", 3)])
+def test_forward_backward_parity(name, B):
+    parity_case(name, B)
+
+
+# The image-resident fused kernels (k_dw_bwd_conv0_s, k_mn_fwd_chain_s: one 512-thread block per CU walks whole images,
+# `for (b = blockIdx.x; b < B; b += gridDim.x)`, with a fetch stream that runs on into the block's NEXT image) launch
+# min(B, CUs) blocks: at the oracle's batch sizes every block has one image and the cross-image branch is dead, at the
+# headline's batch 512 every block walks 2 (32- / 16-wide maps) or 4 (8-wide) images.  MVAE_FUSED_CUS* (read once per
+# process, hence the subprocess) caps the grid at 8 blocks, which puts the multi-image path under the oracle at an
+# affordable batch: c32nb B=20 -> blocks with 3 and 2 images (uneven tail) on 32- / 16- / 8-wide maps, c64nb B=20 likewise on
+# its 32 / 16 / 8 wide scales (plus 64- and 4-wide ones on the other kernels), B=33 -> 5 and 4 images.  Same bars as above.
+# reference: layer_blocks.py:594-641 (mobilenetV3_block forward; its backward per SURVEY appendix C).
+MULTI_IMAGE_ENV = {"MVAE_FUSED_CUS": "8", "MVAE_FUSED_CUS16": "8", "MVAE_FUSED_CUS8": "8"}
+
+
+def _subprocess_case(name, B, tag, env):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "tests.test_parity_gpu", name, str(B), tag], cwd=ROOT, env=e, timeout=600,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-6000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("name,B,det", [("c32nb", 20, "0"), ("c64nb", 20, "0"), ("c32nb", 33, "0"), ("c32nb", 20, "1")])
+def test_multi_image_blocks_parity(name, B, det):
+    env = dict(MULTI_IMAGE_ENV, MVAE_DETERMINISTIC=det)
+    out = _subprocess_case(name, B, "multi_%s_b%d_det%s" % (name, B, det), env)
+    assert "fused launches: fwd" in out and "images per block" in out, out[-2000:]
+
+
+if __name__ == "__main__":          # subprocess body of test_multi_image_blocks_parity
+    import sys
+    _name, _B, _tag = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+
+    def _check(eng):
+        # the case is only worth its time if the fused kernels really ran, with several images per block
+        st = eng.fused_launch_stats()
+        print("fused launches: fwd %d bwd %d, images per block up to %d" % (st["fwd"], st["bwd"], st["max_images_per_block"]))
+        # (the deterministic mode keeps the separate forward launches: the fused forward's GAP order is fixed anyway,
+        # but its squeeze-excite inputs are not -- kernels_fused_fwd.hip)
+        det = os.environ.get("MVAE_DETERMINISTIC", "") == "1"
+        assert (st["fwd"] > 0 or det) and st["bwd"] > 0 and st["max_images_per_block"] >= 2, st
+
+    rep = parity_case(_name, _B, tag=_tag, env_check=_check)
+    print("ok", _tag, "elbo_rel %.2e" % rep["loss/elbo_rel"], "kink flips", rep["kink/flips"])
+
 
 
 @pytest.mark.parametrize("name,B", [("tiny", 4), ("c32nb", 4)])
