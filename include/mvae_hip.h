@@ -163,6 +163,24 @@ int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_sca
 /* forward + backward + apply on one device (keras train_on_batch). */
 int mvae_train_step(mvae_handle* h, const mvae_step_io* io, float r_factor, float kl_factor, float lr,
                     float clip_norm, void* stream);
+/* ---- data-parallel exchange: the batch shards over one process per GPU, every rank holds a parameter
+ *      replica, and ONE all-reduce(sum, float32) of the reduce arena [gradients | BatchNorm batch statistics | metrics] per
+ *      step is the only exchange.  The reference has no counterpart (a single-device keras fit, multiscale_vae.py:550-557);
+ *      these entry points bind RCCL (librccl.so, looked up at run time: a copy already loaded in the process is reused)
+ *      so that a C caller needs nothing else.  The Python facade keeps calling torch.distributed.all_reduce on the same
+ *      arena by default (same RCCL underneath).
+ *      unique_id: rank 0 creates the 128-byte ncclUniqueId and hands it to the other ranks out of band (file, socket, MPI).
+ *      comm_init: collective over all ranks; the handle must be bound (the communicator lives on its device).
+ *      allreduce: in-place sum over reduce-arena floats [offset, offset + count) on `stream`; count < 0 = to the end.
+ *      train_step_dp = forward + backward + allreduce(whole arena) + apply_adagrad(grad_scale = 1 / nranks). ---- */
+#define MVAE_COMM_ID_BYTES 128
+int mvae_comm_unique_id(char id[MVAE_COMM_ID_BYTES]);
+int mvae_comm_init(mvae_handle* h, const char id[MVAE_COMM_ID_BYTES], int32_t rank, int32_t nranks);
+int mvae_comm_destroy(mvae_handle* h);
+int mvae_comm_size(const mvae_handle* h);                /* ranks of the handle's communicator, 0 = none */
+int mvae_allreduce(mvae_handle* h, int64_t offset, int64_t count, void* stream);
+int mvae_train_step_dp(mvae_handle* h, const mvae_step_io* io, float r_factor, float kl_factor, float lr,
+                       float clip_norm, void* stream);
 /* sum of the Keras regularisation losses (added to the reported `loss`) -> 1 float on the device. */
 int mvae_reg_loss(mvae_handle* h, float* out_dev, void* stream);
 /* decoder model (multiscale_vae.py:247-257): z [B,sum z] -> recon [B,H,W,C], inference mode. */

@@ -8,6 +8,7 @@ MVAE_ABI_VERSION = 4
 MVAE_MAX_LEVELS = 16
 MVAE_MAX_BLOCKS = 16
 MVAE_NAME_CAP = 96
+MVAE_COMM_ID_BYTES = 128
 MVAE_OK, MVAE_E_INVALID, MVAE_E_STATE, MVAE_E_HIP, MVAE_E_NOMEM = 0, -1, -2, -3, -4
 REG_NAMES = {0: None, 1: "l1", 2: "l2"}
 ACT_DTYPES = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
@@ -73,6 +74,12 @@ SYMBOLS = {
     "mvae_graph_stats": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mvae_apply_adagrad": (C.c_int, [_H, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mvae_train_step": (C.c_int, [_H, C.POINTER(MvaeStepIO), C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "mvae_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "mvae_comm_init": (C.c_int, [_H, C.c_char_p, C.c_int32, C.c_int32]),
+    "mvae_comm_destroy": (C.c_int, [_H]),
+    "mvae_comm_size": (C.c_int, [_H]),
+    "mvae_allreduce": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_void_p]),
+    "mvae_train_step_dp": (C.c_int, [_H, C.POINTER(MvaeStepIO), C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mvae_reg_loss": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "mvae_decode": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mvae_gather_rows": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -8,6 +8,8 @@
 #include "kernels.h"
 #include "prof.h"
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -161,6 +163,9 @@ struct mvae_handle {
   bool last_training = false;
   const float* last_x = nullptr;
   const float* last_eps = nullptr;
+  // data-parallel exchange bound to RCCL directly (mvae_comm_init): one communicator per handle = per process = per GPU
+  void* comm = nullptr;
+  int comm_rank = 0, comm_nranks = 1;
 };
 
 namespace {
@@ -1116,6 +1121,7 @@ void mvae_destroy(mvae_handle* h) {
     }
     for (hipEvent_t ev : h->ev_pool) (void)hipEventDestroy(ev);
   }
+  (void)mvae_comm_destroy(h);
   delete h;
 }
 
@@ -1602,6 +1608,128 @@ int mvae_train_step(mvae_handle* h, const mvae_step_io* io, float r_factor, floa
   rc = mvae_backward(h, r_factor, kl_factor, stream);
   if (rc != MVAE_OK) return rc;
   return mvae_apply_adagrad(h, lr, clip_norm, 1.0f, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Data-parallel exchange through RCCL, bound without a link-time dependency: librccl is looked up in the process first
+// (a Python caller has torch's copy loaded; the two must not both initialise the same GPU's network state) and opened
+// from the ROCm installation otherwise.  SURVEY 8(b) / 8(e): one ncclAllReduce(sum, float32) over the reduce arena
+// [gradients | BatchNorm batch statistics | metrics] per step on the caller's stream, then the identical clipnorm + Adagrad
+// on every rank with grad_scale = 1 / nranks.
+namespace {
+
+struct RcclId { char internal[MVAE_COMM_ID_BYTES]; };           // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+};
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;                   // rccl.h: ncclFloat32, ncclSum
+
+RcclApi& rccl() {
+  static RcclApi api;
+  if (api.lib || !api.err.empty()) return api;
+  const char* names[] = {getenv("MVAE_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {                                 // a copy already in the process wins (RTLD_NOLOAD)
+    if (n && *n && (api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  }
+  for (const char* n : names) {
+    if (api.lib) break;
+    if (n && *n) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  }
+  if (!api.lib) {
+    api.err = "librccl.so not found (set MVAE_RCCL_LIB)";
+    return api;
+  }
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+  api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
+    api.err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
+    api.lib = nullptr;
+  }
+  return api;
+}
+
+}  // namespace
+
+int mvae_comm_unique_id(char id[MVAE_COMM_ID_BYTES]) {
+  if (!id) return MVAE_E_INVALID;
+  RcclApi& r = rccl();
+  if (!r.lib) return fail(nullptr, MVAE_E_STATE, "%s", r.err.c_str());
+  RcclId u;
+  const int rc = r.GetUniqueId(&u);
+  if (rc != 0) return fail(nullptr, MVAE_E_HIP, "ncclGetUniqueId: %s", r.GetErrorString(rc));
+  memcpy(id, u.internal, MVAE_COMM_ID_BYTES);
+  return MVAE_OK;
+}
+
+int mvae_comm_init(mvae_handle* h, const char id[MVAE_COMM_ID_BYTES], int32_t rank, int32_t nranks) {
+  if (!h || !id) return MVAE_E_INVALID;
+  if (!h->bound) return fail(h, MVAE_E_STATE, "mvae_bind has not been called (the communicator belongs to the bound device)");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, MVAE_E_INVALID, "rank %d outside [0, %d)", rank, nranks);
+  if (h->comm) return fail(h, MVAE_E_STATE, "mvae_comm_init: this handle already has a communicator");
+  RcclApi& r = rccl();
+  if (!r.lib) return fail(h, MVAE_E_STATE, "%s", r.err.c_str());
+  if (hipSetDevice(h->device) != hipSuccess) return fail(h, MVAE_E_HIP, "hipSetDevice(%d) failed", h->device);
+  RcclId u;
+  memcpy(u.internal, id, MVAE_COMM_ID_BYTES);
+  void* comm = nullptr;
+  const int rc = r.CommInitRank(&comm, nranks, u, rank);
+  if (rc != 0 || !comm) return fail(h, MVAE_E_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, r.GetErrorString(rc));
+  h->comm = comm;
+  h->comm_rank = rank;
+  h->comm_nranks = nranks;
+  return MVAE_OK;
+}
+
+int mvae_comm_destroy(mvae_handle* h) {
+  if (!h) return MVAE_E_INVALID;
+  if (h->comm) {
+    (void)hipDeviceSynchronize();
+    (void)rccl().CommDestroy(h->comm);
+    h->comm = nullptr;
+    h->comm_nranks = 1;
+    h->comm_rank = 0;
+  }
+  return MVAE_OK;
+}
+
+int mvae_comm_size(const mvae_handle* h) { return h ? (h->comm ? h->comm_nranks : 0) : MVAE_E_INVALID; }
+
+int mvae_allreduce(mvae_handle* h, int64_t offset, int64_t count, void* stream) {
+  if (!h) return MVAE_E_INVALID;
+  if (!h->bound) return fail(h, MVAE_E_STATE, "mvae_bind has not been called");
+  if (!h->comm) return fail(h, MVAE_E_STATE, "mvae_comm_init has not been called");
+  const int64_t n = h->P + h->S + h->MET;
+  if (count < 0) count = n - offset;
+  if (offset < 0 || count < 0 || offset + count > n)
+    return fail(h, MVAE_E_INVALID, "mvae_allreduce: [%lld, %lld) outside the reduce arena of %lld floats", (long long)offset,
+                (long long)(offset + count), (long long)n);
+  if (count == 0) return MVAE_OK;
+  float* p = h->dr + offset;
+  const int rc = rccl().AllReduce(p, p, (size_t)count, kNcclFloat32, kNcclSum, h->comm, static_cast<hipStream_t>(stream));
+  if (rc != 0) return fail(h, MVAE_E_HIP, "ncclAllReduce: %s", rccl().GetErrorString(rc));
+  return MVAE_OK;
+}
+
+int mvae_train_step_dp(mvae_handle* h, const mvae_step_io* io, float r_factor, float kl_factor, float lr, float clip_norm,
+                       void* stream) {
+  if (!io || !io->training) return h ? fail(h, MVAE_E_INVALID, "mvae_train_step_dp needs io->training = 1") : MVAE_E_INVALID;
+  if (!h || !h->comm) return h ? fail(h, MVAE_E_STATE, "mvae_comm_init has not been called") : MVAE_E_INVALID;
+  int rc = mvae_forward(h, io, stream);
+  if (rc != MVAE_OK) return rc;
+  rc = mvae_backward(h, r_factor, kl_factor, stream);
+  if (rc != MVAE_OK) return rc;
+  rc = mvae_allreduce(h, 0, -1, stream);
+  if (rc != MVAE_OK) return rc;
+  return mvae_apply_adagrad(h, lr, clip_norm, 1.0f / (float)h->comm_nranks, stream);
 }
 
 int mvae_reg_loss(mvae_handle* h, float* out_dev, void* stream) {

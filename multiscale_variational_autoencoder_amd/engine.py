@@ -293,6 +293,45 @@ class Engine:
             scale = 1.0 / dist.get_world_size()
         self.apply(lr, clip_norm, scale)
 
+    # ------------------------------------------------------------------ RCCL bound through the C ABI (mvae_comm_*)
+    def comm_unique_id(self):
+        """128-byte ncclUniqueId (rank 0 creates it and hands it to the other ranks out of band)."""
+        buf = C.create_string_buffer(_abi.MVAE_COMM_ID_BYTES)
+        self._check(self.lib.mvae_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks):
+        """ncclCommInitRank on the handle's device: collective over all ranks."""
+        if len(unique_id) != _abi.MVAE_COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % _abi.MVAE_COMM_ID_BYTES)
+        self._enter()
+        self._check(self.lib.mvae_comm_init(self.h, C.create_string_buffer(bytes(unique_id), _abi.MVAE_COMM_ID_BYTES), int(rank), int(nranks)))
+
+    def comm_size(self):
+        return int(self.lib.mvae_comm_size(self.h))
+
+    def allreduce(self, offset=0, count=-1):
+        self._check(self.lib.mvae_allreduce(self.h, int(offset), int(count), self._stream()))
+
+    def train_step_dp_abi(self, x, lr, r_factor, kl_factor, clip_norm, eps=None, noise=None, keep_mask=None, seed=0):
+        """forward + backward + ncclAllReduce of the reduce arena + Adagrad(grad_scale = 1 / ranks) in ONE C-ABI call."""
+        io = self._step_io(x, eps, noise, keep_mask, seed)
+        self._check(self.lib.mvae_train_step_dp(self.h, C.byref(io), float(r_factor), float(kl_factor), float(lr),
+                                                float(clip_norm if clip_norm else 0.0), self._stream()))
+
+    def _step_io(self, x, eps, noise, keep_mask, seed):
+        io = _abi.MvaeStepIO()
+        io.x, io.batch, io.training, io.seed = x.data_ptr(), int(x.shape[0]), 1, int(seed) & (2 ** 64 - 1)
+        io.eps = eps.data_ptr() if eps is not None else None
+        io.noise = noise.data_ptr() if noise is not None else None
+        io.keep_mask = keep_mask.data_ptr() if keep_mask is not None else None
+        self._keep = (x, eps, noise, keep_mask)
+        self._enter()
+        for t in self._keep:
+            if t is not None:
+                t.record_stream(self.stream)
+        return io
+
     def train_step_abi(self, x, lr, r_factor, kl_factor, clip_norm, eps=None, noise=None, keep_mask=None, seed=0):
         """The single-device step through ONE C-ABI call, mvae_train_step (what INTEGRATION.md binds)."""
         io = _abi.MvaeStepIO()

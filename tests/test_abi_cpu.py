@@ -87,6 +87,13 @@ def test_unbound_handle_refuses_compute(hip_lib):
     assert hip_lib.mvae_backward(eng.h, 1.0, 1.0, None) == _abi.MVAE_E_STATE
     assert hip_lib.mvae_apply_adagrad(eng.h, 1e-3, 1.0, 1.0, None) == _abi.MVAE_E_STATE
     assert hip_lib.mvae_bind(eng.h, 0, None, None, None, None, None, 0) == _abi.MVAE_E_INVALID
+    # the RCCL entry points: no communicator without a bound device, no exchange without a communicator
+    ident = C.create_string_buffer(_abi.MVAE_COMM_ID_BYTES)
+    assert hip_lib.mvae_comm_init(eng.h, ident, 0, 1) == _abi.MVAE_E_STATE
+    assert hip_lib.mvae_comm_size(eng.h) == 0
+    assert hip_lib.mvae_allreduce(eng.h, 0, -1, None) == _abi.MVAE_E_STATE
+    assert hip_lib.mvae_train_step_dp(eng.h, C.byref(io), 1.0, 1.0, 1e-3, 1.0, None) == _abi.MVAE_E_STATE
+    assert hip_lib.mvae_comm_destroy(eng.h) == _abi.MVAE_OK
     p, n = C.c_void_p(), C.c_int64()
     assert hip_lib.mvae_tensor_lookup(eng.h, b"enc0.b0.mn.t1", C.byref(p), C.byref(n)) == _abi.MVAE_OK
     assert p.value is None and n.value == 4 * 4 * 8

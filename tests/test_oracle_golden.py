@@ -88,6 +88,25 @@ def test_bilinear_and_blur_restatements_agree():
     assert np.abs(np_ops.gaussian_blur_nhwc(x) - bl).max() < 1e-12
 
 
+def test_depthwise_taps_equal_grouped_convolution():
+    """The oracle writes DepthwiseConv2D (layer_blocks.py:604-614) and the fixed blur as nine shifted multiply-adds (speed:
+    torch runs a float64 grouped convolution as C separate convolutions); same values and same gradients as
+    F.conv2d(groups=C), and the same result as the loop-level numpy restatement."""
+    from oracle.mvae_oracle import depthwise3x3_same
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 7, 9, dtype=torch.float64, generator=g, requires_grad=True)
+    w = torch.randn(3, 3, 5, 1, dtype=torch.float64, generator=g, requires_grad=True)
+    b = torch.randn(5, dtype=torch.float64, generator=g, requires_grad=True)
+    y = depthwise3x3_same(x, w, b)
+    ref = F.conv2d(F.pad(x, (1, 1, 1, 1)), w.permute(2, 3, 0, 1), b, groups=5)
+    assert (y - ref).abs().max().item() <= 1e-14
+    up = torch.randn(y.shape, dtype=torch.float64, generator=g)
+    ga = torch.autograd.grad(y, (x, w, b), up, retain_graph=True)
+    gb = torch.autograd.grad(ref, (x, w, b), up)
+    for a, r in zip(ga, gb):
+        assert (a - r).abs().max().item() <= 1e-13
+
+
 def test_param_census_matches_survey():       # SURVEY.md 8 census table
     from tests.common import NB
     for dims, z, enc, want, ntens in [((32, 32, 3), [16] * 3, NB, 1295625, 420), ((32, 32, 3), [16] * 3, None, 2138313, None),
@@ -146,8 +165,8 @@ def test_kink_mask_override_is_the_identity_on_the_oracles_own_active_sets():
     rep = o.kink_report()
     assert rep["flips"] == 0 and rep["units"] > 0
     assert res2["loss"] == res["loss"]
-    for k in G:
-        assert np.array_equal(G[k], G2[k]), k
+    for k in G:      # (to rounding: autograd adds the nine tap gradients of a depthwise layer in no fixed order)
+        assert np.abs(G[k] - G2[k]).max() <= 1e-12 * max(1.0, np.abs(G[k]).max()), k
     key = next(k for k in masks if k.endswith(".t0"))
     flipped = dict(masks)
     flipped[key] = masks[key].copy()
@@ -156,7 +175,7 @@ def test_kink_mask_override_is_the_identity_on_the_oracles_own_active_sets():
     o.set_kink_masks(flipped)
     res3, G3 = o.loss_and_grads(*args)
     assert o.kink_report()["flips"] == 1 and o.kink_report()["max_abs_at_flip"] > 0
-    assert any(not np.array_equal(G[k], G3[k]) for k in G)
+    assert any(np.abs(G[k] - G3[k]).max() > 1e-9 * max(1.0, np.abs(G[k]).max()) for k in G)
 
 
 def _block_params(kind, channels, filters=32, squeeze_units=-1, seed=0):

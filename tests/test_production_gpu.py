@@ -165,6 +165,47 @@ def test_rccl_allreduce_branch_world1(tmp_path):
     assert np.isfinite(f["allreduce_ms"]).all() and (f["allreduce_ms"] > 0).all()
 
 
+def test_comm_abi_world1_equals_plain_step():
+    """mvae_comm_init / mvae_allreduce / mvae_train_step_dp bind librccl directly (no torch.distributed).
+    A one-rank communicator through the C ABI: the all-reduce is the identity and grad_scale = 1, so the step must equal
+    mvae_train_step within float-atomic noise; the arena sub-range form and the error paths are exercised too."""
+    name, B = "c32nb", 8
+    io = make_inputs(name, B)
+    runs = []
+    for dp in (False, True):
+        eng = _engine(name, B)
+        eng.set_params(io["params"]); eng.set_state(io["state"])
+        d = {k: eng.to_device(io[k]) for k in ("x", "eps", "noise", "keep")}
+        if dp:
+            assert eng.comm_size() == 0
+            with pytest.raises(RuntimeError, match="mvae_comm_init"):
+                eng.allreduce()
+            eng.comm_init(eng.comm_unique_id(), 0, 1)
+            assert eng.comm_size() == 1
+            with pytest.raises(RuntimeError, match="already has a communicator"):
+                eng.comm_init(eng.comm_unique_id(), 0, 1)
+        for step in range(3):
+            fn = eng.train_step_dp_abi if dp else eng.train_step_abi
+            fn(d["x"], COMPILE["learning_rate"], COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"], COMPILE["clip_norm"],
+               eps=d["eps"], noise=d["noise"], keep_mask=d["keep"])
+        eng.sync()
+        if dp:
+            before = eng.reduce.clone()
+            eng.allreduce(0, eng.reduce_split if eng.reduce_split > 0 else 1024)     # a leading sub-range, in place
+            eng.allreduce(16, -1)
+            eng.sync()
+            assert eng.torch.equal(before, eng.reduce)                               # sum over one rank = identity
+            with pytest.raises(ValueError, match="outside the reduce arena"):
+                eng.allreduce(0, before.numel() + 1)
+        runs.append((eng.tensor("losses", B).cpu().numpy().copy(), eng.get_params()))
+        eng.close()
+    (la, pa), (lb, pb) = runs
+    assert rel_err(la, lb) <= 1e-5
+    lr = COMPILE["learning_rate"]
+    for k in pa:
+        assert np.abs(pa[k] - pb[k]).max() <= 0.05 * lr * 3, k
+
+
 def test_input_pipeline_feeds_the_right_batches():
     """train() used to hand every step a fresh default-stream tensor that the allocator could recycle
     while the engine's stream still read it.  Here the dataset is constant per image (image i is all i), batches are
