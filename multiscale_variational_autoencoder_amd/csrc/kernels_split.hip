@@ -400,12 +400,18 @@ __global__ void k_selftest_compare(const unsigned* __restrict__ got, const unsig
 
 static int g_split_state = -1;                 // -1 untested, 1 usable, 2 disabled by the self-test
 static int g_split_erratum = -1;               // wrong values the PACKED check kernel returned (-1 = not measured)
+static int g_k16_erratum = -1;                 // the same beside the bfloat16-storage kernels (k16_taps) as the neighbour
 int split_conv_status() { return !split_enabled() ? 0 : (g_split_state == 2 ? 2 : 1); }
 int split_conv_erratum_count() { return g_split_erratum; }
+int k16_erratum_count() { return g_k16_erratum; }
+// kernels_bf16.hip: the bf16-storage 5x5 kernels (float32 VALU for bias / conversion between v_mfma_f32_32x32x16_bf16)
+bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g,
+                   hipStream_t s, const float* w2, const float* bias2, void* out2, bool* chained);
 
 // One measurement: the split kernels on one stream, check kernel `vv` back to back on another; number of wrong values,
 // or -1 if it could not run.  vv: 0 = as this library is compiled, 1 = v_fma_f32, 2 = integer, 3 = v_pk_fma_f32 (asm), 4 = compiled with packed float32;
-// conv: 0 = split kernels, 1 = float32-MFMA kernels (control)
+// conv: 0 = split kernels, 1 = float32-MFMA kernels (control), 2 = the bfloat16-storage kernels (k16_taps: the tensors are then
+// read as bf16 -- same byte footprint or less, values irrelevant to what is measured)
 static long selftest_run(int vv, int conv, int VB) {
   const int nb = 256, Z = 16, N = 32768, NV = 96 * 2 / VB > 8 ? 96 * 2 / VB : 8, ROUNDS = 6;
   ConvGeom g{nb, 32, 32, 64, 16, 16, 32, 5, 5, 2, 2, 1, 1};        // decoder layer: T-form 32 -> 64 and F-form 64 -> 32
@@ -445,6 +451,9 @@ static long selftest_run(int vv, int conv, int VB) {
         if (conv == 1) {
           launch_conv_taps_mfma(true, small, w, nullptr, big, g, sa);
           launch_conv_taps_mfma(false, big, w, nullptr, small, g, sa);
+        } else if (conv == 2) {
+          if (!launch16_taps(true, small, w, nullptr, big, g, sa, nullptr, nullptr, nullptr, nullptr) ||
+              !launch16_taps(false, big, w, nullptr, small, g, sa, nullptr, nullptr, nullptr, nullptr)) ok = false;
         } else {
           launch_conv_taps_split(true, small, planes, nullptr, big, g, sa);
           launch_conv_taps_split(false, big, planes, nullptr, small, g, sa);
@@ -485,6 +494,8 @@ bool split_selftest() {
   const long shipped = selftest_run(0, 0, 2);      // the instructions this library is built from
   const long packed = selftest_run(4, 0, 2);       // the same source compiled WITH packed float32: reports the erratum itself
   g_split_erratum = (int)(packed < 0 ? -1 : (packed > 2000000000L ? 2000000000L : packed));
+  const long packed16 = selftest_run(4, 2, 2);     // ... and beside the bfloat16-storage kernels (are THEY such a neighbour?)
+  g_k16_erratum = (int)(packed16 < 0 ? -1 : (packed16 > 2000000000L ? 2000000000L : packed16));
   g_split_state = shipped > 0 ? 2 : 1;
   if (shipped > 0 || mode >= 2)
     fprintf(stderr, "mvae: split-bf16 convolution self-test: %ld wrong values in the check kernel as compiled, %ld in its "

@@ -1041,6 +1041,11 @@ int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
 int mvae_deterministic(const mvae_handle* h) { return h ? (h->det ? 1 : 0) : MVAE_E_INVALID; }
 int mvae_split_conv_status(void) { return split_conv_status(); }
 int mvae_split_conv_erratum(void) { return split_conv_erratum_count(); }
+int mvae_packed_f32_hazard(int32_t* beside_split, int32_t* beside_bf16) {
+  if (beside_split) *beside_split = split_conv_erratum_count();
+  if (beside_bf16) *beside_bf16 = k16_erratum_count();
+  return MVAE_OK;
+}
 int mvae_fused_launch_stats(int32_t* fwd, int32_t* bwd, int32_t* max_images_per_block) {
   int v[3];
   fused_launch_stats(v);

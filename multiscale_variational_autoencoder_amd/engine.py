@@ -231,7 +231,26 @@ class Engine:
         arena (137 of 144 MB for the 256x256 configurations) travelling while the encoder half of the backward pass still
         runs.  OFF by default: no multi-GPU RCCL run has yet shown it bitwise-equal to the single-message path and faster
         (it has only run over gloo on one GPU and over RCCL at world size 1, where the all-reduce is a no-op)."""
-        return os.environ.get("MVAE_DP_OVERLAP", "") == "1" and self.reduce_split > 0
+        mode = os.environ.get("MVAE_DP_OVERLAP", "")
+        if mode not in ("1", "force") or self.reduce_split <= 0:
+            return False
+        if mode == "1" and max(self.packed_f32_hazard()) > 0:
+            # RCCL's float32 reduce kernels contain v_pk_*_f32 (tools/rccl_isa_scan.py); this board returned wrong values
+            # from such instructions beside this library's bf16-MFMA kernels (the bind-time self-test): no overlap here.
+            if not getattr(self, "_overlap_warned", False):
+                self._overlap_warned = True
+                import warnings
+                warnings.warn("MVAE_DP_OVERLAP=1 refused: the packed-float32 hazard self-test counted %d / %d wrong values "
+                              "on this GPU and RCCL's reduce kernels use packed float32; single-message exchange instead "
+                              "(MVAE_DP_OVERLAP=force overrides)" % self.packed_f32_hazard())
+            return False
+        return True
+
+    def packed_f32_hazard(self):
+        """(wrong packed-float32 values beside the split-bf16 kernels, beside the bf16-storage kernels); -1 = not measured."""
+        a, b = C.c_int32(-1), C.c_int32(-1)
+        self.lib.mvae_packed_f32_hazard(C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def apply(self, lr, clip_norm, grad_scale=1.0):
         self._check(self.lib.mvae_apply_adagrad(self.h, float(lr), float(clip_norm if clip_norm else 0.0),

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, name, B, overlap="0"):
+def _worker(rank, world, port, out_dir, name, B, overlap="0", act="f32"):
     os.environ["MVAE_DP_OVERLAP"] = overlap
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,7 +30,7 @@ def _worker(rank, world, port, out_dir, name, B, overlap="0"):
     io = make_inputs(name, B)
     per = B // world
     sl = slice(rank * per, (rank + 1) * per)
-    eng = Engine(**engine_args(name, per)).bind(0)
+    eng = Engine(**engine_args(name, per), act_dtype=act).bind(0)
     eng.set_params(io["params"]); eng.set_state(io["state"])
     d = {k: eng.to_device(io[k][sl]) for k in ("x", "eps", "noise", "keep")}
     eng.train_step(d["x"], COMPILE["learning_rate"], COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"],
@@ -45,9 +45,9 @@ def _worker(rank, world, port, out_dir, name, B, overlap="0"):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("name,B,overlap", [("tiny", 8, "0"), ("c32nb", 8, "0"), ("c32nb", 8, "1")])
+@pytest.mark.parametrize("name,B,overlap", [("tiny", 8, "0"), ("c32nb", 8, "0"), ("c32nb", 8, "force")])
 def test_engine_dp2_matches_oracle_with_per_replica_batchnorm(tmp_path, name, B, overlap):
-    """overlap = "1": the two-phase backward with the Dense-weight region all-reduced while phase 1 runs."""
+    """overlap = "force": the two-phase backward with the Dense-weight region all-reduced while phase 1 runs."""
     import torch.multiprocessing as mp
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), name, B, overlap), nprocs=world, join=True)
@@ -77,3 +77,56 @@ def test_engine_dp2_matches_oracle_with_per_replica_batchnorm(tmp_path, name, B,
     assert float(r0["count"]) == B                        # metrics block is part of the same all-reduce
     assert abs(float(r0["r_exp"]) - float(np.mean(res["r_exp"]))) <= 1e-4 * abs(float(np.mean(res["r_exp"])))
     assert abs(float(r0["kl"]) - float(np.mean(res["kl"]))) <= 1e-4 * abs(float(np.mean(res["kl"]))) + 1e-6
+
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("overlap", ["0", "force"])
+def test_engine_dp2_bf16_c64nb(tmp_path, overlap):
+    """BASELINE config 5's combination (bf16 activations + data parallel; here the 64x64 / 5-scale shrink of C256-nb, two
+    ranks of 4 images sharing one GPU over gloo, single-message and two-phase exchange).  What data parallelism adds is
+    exact -- the all-reduce sums float32 arenas -- so the replicas must stay bit-identical; against the float64 oracle
+    with per-replica BatchNorm groups the bars are the bf16 class of tests/test_bf16_gpu.py (a 4-image replica: its
+    batch-2 bars): per tensor, the relative error of the applied UPDATE (Adagrad's first step is lr * g / sqrt(0.1 + g^2):
+    at most the gradient's relative error) <= 0.2 for weights, median <= 1.5e-2; metrics <= 2e-2; BatchNorm moving
+    statistics <= 2e-2."""
+    import json
+    import torch.multiprocessing as mp
+    name, B, world = "c64nb", 8, 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), name, B, overlap, "bf16"), nprocs=world, join=True)
+    from oracle.mvae_oracle import Oracle
+    io = make_inputs(name, B)
+    orc = Oracle(oracle_config(name))
+    p0 = {k: np.asarray(v, np.float64) for k, v in io["params"].items()}
+    a0 = {k: np.full(v.shape, 0.1) for k, v in p0.items()}
+    st0 = {k: np.asarray(v, np.float64) for k, v in io["state"].items()}
+    res, G, p1, a1, st1 = orc.train_step(p0, a0, st0, io["x"], io["eps"], io["noise"], io["keep"],
+                                         COMPILE["learning_rate"], COMPILE["r_loss_factor"], COMPILE["kl_loss_factor"],
+                                         COMPILE["clip_norm"], bn_group_size=B // world)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    zero = structurally_zero(G)
+    errs, worst_w, worst_v = [], ("", 0.0), ("", 0.0)
+    for k in p1:
+        assert np.array_equal(r0["p/" + k], r1["p/" + k]), k            # replicas stay identical
+        assert np.array_equal(r0["a/" + k], r1["a/" + k]), k
+        if k in zero:
+            continue
+        step = p1[k] - p0[k]
+        e = float(np.linalg.norm((r0["p/" + k] - p1[k]).ravel()) / max(np.linalg.norm(step.ravel()), 1e-30))
+        errs.append(e)
+        if p1[k].ndim >= 2:
+            worst_w = max(worst_w, (k, e), key=lambda kv: kv[1])
+        else:
+            worst_v = max(worst_v, (k, e), key=lambda kv: kv[1])
+    st_err = max(rel_err(r0["s/" + k], np.asarray(v)) for k, v in st1.items())
+    rep = {"median": float(np.median(errs)), "p90": float(np.percentile(errs, 90)), "worst_weight": worst_w,
+           "worst_vector": worst_v, "state": st_err,
+           "r_exp": abs(float(r0["r_exp"]) / float(np.mean(res["r_exp"])) - 1.0),
+           "kl": abs(float(r0["kl"]) / float(np.mean(res["kl"])) - 1.0)}
+    from tests.common import ROOT
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "dp2_bf16_c64nb_overlap%s.json" % overlap), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert float(r0["count"]) == B
+    assert rep["median"] <= 1.5e-2 and rep["worst_weight"][1] <= 0.2, rep
+    assert rep["r_exp"] <= 2e-2 and rep["kl"] <= 2e-2 and rep["state"] <= 2e-2, rep

@@ -120,7 +120,7 @@ def _rccl_worker(rank, port, out_dir):
     io = make_inputs(name, B)
     out = {}
     for tag, force in (("plain", False), ("rccl", True), ("overlap", True)):
-        os.environ["MVAE_DP_OVERLAP"] = "1" if tag == "overlap" else "0"     # overlap: two-phase backward, two collectives
+        os.environ["MVAE_DP_OVERLAP"] = "force" if tag == "overlap" else "0"     # overlap: two-phase backward, two collectives
         eng = _engine(name, B)
         assert eng.reduce_split > 0
         eng.set_params(io["params"]); eng.set_state(io["state"])
@@ -163,6 +163,28 @@ def test_rccl_allreduce_branch_world1(tmp_path):
         assert np.abs(f["plain/" + k] - f["rccl/" + k]).max() <= 0.05 * lr * 3, k
         assert np.abs(f["plain/" + k] - f["overlap/" + k]).max() <= 0.05 * lr * 3, k
     assert np.isfinite(f["allreduce_ms"]).all() and (f["allreduce_ms"] > 0).all()
+
+
+def test_dp_overlap_is_refused_while_the_packed_f32_hazard_is_present(monkeypatch):
+    """MVAE_DP_OVERLAP=1 runs RCCL's reduce kernels beside the backward pass.  Those kernels contain v_pk_*_f32
+    (profiles/round4_rccl_packed_f32_scan.json) and the bind-time self-test measures, per board, whether such instructions
+    return wrong values beside this library's bf16-MFMA kernels: the engine keeps the single message while either count is
+    non-zero ("force" overrides: the one-GPU rehearsals use it, their collective is gloo or a one-rank no-op)."""
+    eng = _engine("c256nb", 1)                      # 137 MB Dense region: the only configuration with a split arena
+    assert eng.reduce_split > 0
+    hz = eng.packed_f32_hazard()
+    assert min(hz) >= 0, hz                         # both measurements ran
+    monkeypatch.setenv("MVAE_DP_OVERLAP", "1")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert eng.dp_overlap_active() == (max(hz) == 0)
+    monkeypatch.setenv("MVAE_DP_OVERLAP", "force")
+    assert eng.dp_overlap_active()
+    monkeypatch.setenv("MVAE_DP_OVERLAP", "0")
+    assert not eng.dp_overlap_active()
+    print("packed-f32 hazard beside split kernels / bf16 kernels:", hz)
+    eng.close()
 
 
 def test_comm_abi_world1_equals_plain_step():
