@@ -89,7 +89,7 @@ def build_tools(verbose=False):
     runs it on the GPU box; built here because the box has no reason to have a compiler warmed up)."""
     root = os.path.dirname(HERE)
     if os.environ.get("MVAE_BUILD_PROBES", "") == "1":     # timing probes linked against the same objects (not run by tests)
-        for name in ("dual_probe.cpp",):
+        for name in ("dual_probe.cpp", "conv_probe_s.cpp"):
             _build_tool(os.path.join(root, "tools", name), verbose)
     return _build_tool(os.path.join(root, "tools", "bf16_unit.hip"), verbose)
 

@@ -271,6 +271,219 @@ k_conv_taps_s(const float* __restrict__ in, const char* __restrict__ Wp, const f
   }
 }
 
+// =================================================================================================
+// T-form with the four sub-pixel phases of a stride-2 5 x 5 transposed convolution MERGED in one block (round 4).
+// Output pixel (2 cy + py, 2 cx + px) sums the taps kh = py + 1 - 2 dy, kw = px + 1 - 2 dx over the input pixels
+// (cy + dy, cx + dx), dy, dx in {-1, 0, 1}: the 25 taps of the four phases read only NINE distinct input offsets
+// (2 x 2, 2, 2 or 1 taps per offset).  k_conv_taps_s<.., TFORM = true> runs one phase per block and gathers its 32 pixels
+// once per TAP -- 25 gathers and 25 three-plane splits per 4 output pixels, in 4096 short blocks (4 - 9 taps each: the
+// pipeline fill of a block is as long as its work).  Here a block owns 128 input-grid positions and all four phases of
+// them: 9 gathers / splits, 25 taps into acc[phase], 1024 blocks of 25 taps.  Requires IH = 2 OH, IW = 2 OW, PT = PL = 1.
+// Tap order: the offsets with four taps first, the single-tap corner last; the next offset's pixels are fetched at the
+// first tap of the current offset and split between the MFMA groups of its last tap.
+// =================================================================================================
+template <int KC, int NC, int NW>
+struct ConvTMergedS {
+  static constexpr int NT = NC / 32, KK = KC / 16, Q = KC / 8;
+  static constexpr int CPP = KC / 4, PPI = 64 / CPP;
+  static constexpr int PLANE_W = NC * KC * 2, TAPB = 3 * PLANE_W;
+  static constexpr int PLANE_A = 32 * KC * 2;
+  static constexpr int NTHR = 64 * NW;
+  static constexpr int WLD = (TAPB + NTHR * 16 - 1) / (NTHR * 16);
+  static constexpr bool WRAG = TAPB % (NTHR * 16) != 0;
+  static constexpr int PF = 2;                                       // weight slices of register prefetch
+  // offset list (dy, dx): 4-tap offsets, 2-tap offsets, the 1-tap corner
+  static __device__ __forceinline__ constexpr int o_dy(int oi) { return oi == 0 ? 0 : oi == 1 ? 0 : oi == 2 ? -1 : oi == 3 ? -1 : oi == 4 ? 1 : oi == 5 ? 1 : oi == 6 ? 0 : oi == 7 ? -1 : 1; }
+  static __device__ __forceinline__ constexpr int o_dx(int oi) { return oi == 0 ? 0 : oi == 1 ? -1 : oi == 2 ? 0 : oi == 3 ? -1 : oi == 4 ? 0 : oi == 5 ? -1 : oi == 6 ? 1 : oi == 7 ? 1 : 1; }
+  static __device__ __forceinline__ constexpr int o_start(int oi) { return oi < 4 ? 4 * oi : (oi < 8 ? 16 + 2 * (oi - 4) : 24); }
+  static __device__ __forceinline__ constexpr int t_oi(int t) { return t < 16 ? t / 4 : (t < 24 ? 4 + (t - 16) / 2 : 8); }
+  static __device__ __forceinline__ constexpr int t_py(int t) {
+    const int oi = t_oi(t), j = t - o_start(oi), nx = o_dx(oi) == 1 ? 1 : 2;
+    return o_dy(oi) == 1 ? 1 : j / nx;
+  }
+  static __device__ __forceinline__ constexpr int t_px(int t) {
+    const int oi = t_oi(t), j = t - o_start(oi), nx = o_dx(oi) == 1 ? 1 : 2;
+    return o_dx(oi) == 1 ? 1 : j % nx;
+  }
+  static __device__ __forceinline__ constexpr int t_kh(int t) { return t_py(t) + 1 - 2 * o_dy(t_oi(t)); }
+  static __device__ __forceinline__ constexpr int t_kw(int t) { return t_px(t) + 1 - 2 * o_dx(t_oi(t)); }
+  static __device__ __forceinline__ constexpr bool t_first(int t) { return t == o_start(t_oi(t)); }
+  static __device__ __forceinline__ constexpr bool t_last(int t) { return t == 24 || t + 1 == o_start(t_oi(t) + 1); }
+
+  static __device__ __forceinline__ void run(const float* __restrict__ in, const char* __restrict__ Wp,
+                                             const float* __restrict__ bias, float* __restrict__ out, const ConvGeom& g,
+                                             unsigned in_bytes, unsigned out_bytes, char (*sW)[TAPB], char* myA, unsigned p0,
+                                             unsigned Mc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int CH = g.OH, CW = g.OW;                                  // the input (small) grid = the phase grid
+    const int lp = lane / CPP, ch = lane % CPP;
+    unsigned base[Q], inv[Q];
+    const bool pow2 = (CW & (CW - 1)) == 0 && (CH & (CH - 1)) == 0;
+    const int lgw = 31 - __builtin_clz((unsigned)CW), lgh = 31 - __builtin_clz((unsigned)CH);
+    auto split = [&](unsigned p, int& cx, int& cy, int& b) {
+      if (pow2) { cx = (int)(p & (unsigned)(CW - 1)); cy = (int)((p >> lgw) & (unsigned)(CH - 1)); b = (int)(p >> (lgw + lgh)); }
+      else { cx = (int)(p % (unsigned)CW); const unsigned q = p / (unsigned)CW; cy = (int)(q % (unsigned)CH); b = (int)(q / (unsigned)CH); }
+    };
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const unsigned p = p0 + wave * 32 + lp + PPI * j;
+      int cx, cy, b;
+      split(p < Mc ? p : 0u, cx, cy, b);
+      base[j] = (unsigned)(((b * CH + cy) * CW + cx) * KC + ch * 4) * 4u;
+      unsigned m = p < Mc ? 0u : 0x77u;                      // bit dy + 1: row cy + dy leaves the image; bit 4 + dx + 1: column
+      if (cy == 0) m |= 1u;
+      if (cy == CH - 1) m |= 4u;
+      if (cx == 0) m |= 0x10u;
+      if (cx == CW - 1) m |= 0x40u;
+      inv[j] = m;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00020000);
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ph][nt][r] = 0.f;
+
+    u32x4 wreg[PF][WLD], areg[Q];
+    auto fetch_w = [&](int t, int slot) {
+      const u32x4* wt = reinterpret_cast<const u32x4*>(Wp + (size_t)(t_kh(t) * 5 + t_kw(t)) * TAPB);
+#pragma unroll
+      for (int u = 0; u < WLD; ++u) {
+        const int idx = (int)threadIdx.x + u * NTHR;
+        wreg[slot][u] = wt[(WRAG && idx * 16 >= TAPB) ? (int)threadIdx.x : idx];
+      }
+    };
+    auto fetch_a = [&](int oi) {
+      const int dy = o_dy(oi), dx = o_dx(oi);
+      const unsigned delta = (unsigned)((dy * CW + dx) * KC * 4);
+      const unsigned sel = (1u << (dy + 1)) | (0x10u << (dx + 1));
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        const unsigned off = (inv[j] & sel) ? 0x80000000u : base[j] + delta;
+        areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+      }
+    };
+    u32x2 sp[Q][3];
+    auto split_slot = [&](int j) { split4(areg[j], sp[j][0], sp[j][1], sp[j][2]); };
+    auto store_w = [&](int slot, int buf) {
+#pragma unroll
+      for (int u = 0; u < WLD; ++u) {
+        const int idx = (int)threadIdx.x + u * NTHR;
+        if (!WRAG || idx * 16 < TAPB) reinterpret_cast<u32x4*>(sW[buf])[idx] = wreg[slot][u];
+      }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        const int pl = lp + PPI * j;
+        const int o = tile_off<KC>(pl, ch >> 1) + (ch & 1) * 8;
+        *reinterpret_cast<u32x2*>(myA + o) = sp[j][0];
+        *reinterpret_cast<u32x2*>(myA + PLANE_A + o) = sp[j][1];
+        *reinterpret_cast<u32x2*>(myA + 2 * PLANE_A + o) = sp[j][2];
+      }
+    };
+    fetch_a(0);
+#pragma unroll
+    for (int t = 0; t < PF; ++t) fetch_w(t, t);
+#pragma unroll
+    for (int j = 0; j < Q; ++j) split_slot(j);
+    store_a();
+    store_w(0, 0);
+    constexpr int GROUPS = KK * NT;
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+      __syncthreads();       // sW[t & 1] and the wave's A tile are complete, sW[(t + 1) & 1] is free
+      if (t_first(t) && t_oi(t) + 1 < 9) fetch_a(t_oi(t) + 1);       // the registers the LDS tile was split from are free
+      if (t + PF < 25) fetch_w(t + PF, t % PF);
+      __builtin_amdgcn_sched_barrier(0);
+      const char* w = sW[t & 1];
+      const int ph = t_py(t) * 2 + t_px(t);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        bf16x8 xa[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          xa[p] = as_frag(*reinterpret_cast<const u32x4*>(myA + p * PLANE_A + tile_off<KC>(i, 2 * kk + h)));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          bf16x8 wb[3];
+          const int wo = wrow_off<KC>(nt * 32 + i, 2 * kk + h);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) wb[p] = as_frag(*reinterpret_cast<const u32x4*>(w + p * PLANE_W + wo));
+          acc[ph][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[2], wb[0], acc[ph][nt], 0, 0, 0);
+          acc[ph][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1], wb[1], acc[ph][nt], 0, 0, 0);
+          acc[ph][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], wb[2], acc[ph][nt], 0, 0, 0);
+          acc[ph][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1], wb[0], acc[ph][nt], 0, 0, 0);
+          acc[ph][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], wb[1], acc[ph][nt], 0, 0, 0);
+          acc[ph][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], wb[0], acc[ph][nt], 0, 0, 0);
+          if (t_last(t) && t < 24) {                        // the next offset's split behind the groups of this offset's last tap
+            constexpr int PER = (Q + GROUPS - 1) / GROUPS;
+            const int gi = kk * NT + nt;
+#pragma unroll
+            for (int j = gi * PER; j < (gi + 1) * PER && j < Q; ++j) split_slot(j);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (t + 1 < 25) store_w((t + 1) % PF, (t + 1) & 1);
+      if (t_last(t) && t < 24) store_a();                  // wave-private tile: this wave's fragment reads of it are done
+    }
+    // ---- epilogue: per phase the pixel (2 cy + py, 2 cx + px); row offsets through the idle A tile
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias ? bias : in)[nt * 32 + i];
+    unsigned* sOff = reinterpret_cast<unsigned*>(myA);
+    __builtin_amdgcn_wave_barrier();
+    if (h == 0) {
+      const unsigned p = p0 + wave * 32 + i;
+      unsigned off = 0x80000000u;
+      if (p < Mc) {
+        int cx, cy, b;
+        split(p, cx, cy, b);
+        off = (unsigned)(((b * g.IH + cy * 2) * g.IW + cx * 2) * NC) * 4u;
+      }
+      sOff[i] = off;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned offs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) offs[r] = sOff[(r & 3) + 8 * (r >> 2) + 4 * h];
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)out_bytes, 0x00020000);
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      const unsigned pho = (unsigned)(((ph >> 1) * g.IW + (ph & 1)) * NC) * 4u;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const unsigned n4 = (unsigned)(nt * 32 + i) * 4u + pho;
+        const float b = bias ? bv[nt] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)      // (an out-of-range row offset 0x80000000 stays out of range with the phase added)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[ph][nt][r] + b), orsrc, offs[r] + n4, 0, 0);
+      }
+    }
+  }
+};
+
+template <int KC, int NC, int NW>
+__global__ void __launch_bounds__(64 * NW, KC == 32 ? 2 : 2)
+k_convt_merged_s(const float* __restrict__ in, const char* __restrict__ Wp, const float* __restrict__ bias,
+                 float* __restrict__ out, ConvGeom g, unsigned in_bytes, unsigned out_bytes) {
+  constexpr int TAPB = 3 * NC * KC * 2, PLANE_A = 32 * KC * 2;
+  __shared__ __attribute__((aligned(16))) char sW[2][TAPB];
+  __shared__ __attribute__((aligned(16))) char sA[NW][3 * PLANE_A];
+  const int wave = threadIdx.x >> 6;
+  const unsigned Mc = (unsigned)(g.B * g.OH * g.OW);
+  const unsigned p0 = blockIdx.x * (32u * NW);
+  if (p0 >= Mc) return;                         // block-uniform
+  ConvTMergedS<KC, NC, NW>::run(in, Wp, bias, out, g, in_bytes, out_bytes, sW, sA[wave], p0, Mc);
+}
+
 int64_t split_planes_bytes(const ConvGeom& g);
 bool launch_conv_taps_mfma(bool transposed, const float* in, const float* w, const float* bias, float* out, const ConvGeom& g,
                            hipStream_t s);           // kernels_mfma.hip (the self-test's control experiment)
@@ -811,6 +1024,16 @@ bool launch_conv_taps_split(bool transposed, const float* in, const void* planes
   const int taps = g.KH * g.KW;
   const char* pF = static_cast<const char*>(planes);
   const char* pT = pF + (int64_t)taps * 3 * g.CI * g.CO * 2;
+  // transposed, stride 2, even sizes, SAME padding of a 5 x 5 kernel: the four sub-pixel phases merged in one block
+  static const bool merged = [] { const char* e = getenv("MVAE_CONVT_MERGED"); return e ? atoi(e) != 0 : true; }();
+  if (transposed && merged && g.IH == 2 * g.OH && g.IW == 2 * g.OW && g.PT == 1 && g.PL == 1) {
+    const char* pTm = static_cast<const char*>(planes) + (int64_t)g.KH * g.KW * 3 * g.CI * g.CO * 2;
+    const int64_t Mm = (int64_t)g.B * g.OH * g.OW;
+    const dim3 gm((unsigned)((Mm + 127) / 128));
+    if (g.CO == 32) hipLaunchKernelGGL((k_convt_merged_s<32, 64, 4>), gm, dim3(256), 0, s, in, pTm, bias, out, g, in_bytes, out_bytes);
+    else hipLaunchKernelGGL((k_convt_merged_s<64, 32, 4>), gm, dim3(256), 0, s, in, pTm, bias, out, g, in_bytes, out_bytes);
+    return true;
+  }
   // PF taps of register prefetch: 3 where a tap's pixels are 16 registers (KC = 32), 2 where they are 32 (KC = 64)
 #define MVAE_CS(A, B_, TF, PF_, P) hipLaunchKernelGGL((k_conv_taps_s<A, B_, TF, PF_, 4>), grid, dim3(256), 0, s, in, P, bias, out, g, in_bytes, out_bytes)
   if (!transposed) { if (g.CI == 32) MVAE_CS(32, 64, false, 3, pF); else MVAE_CS(64, 32, false, 2, pF); }

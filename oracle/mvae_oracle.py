@@ -228,6 +228,10 @@ class _Depthwise3x3(torch.autograd.Function):
 
 
 def _depthwise3x3_taps(x, w_hwc, b):
+    if x.dtype != torch.float64:
+        # float32 (the timed CPU baseline of bench.py): torch's grouped convolution is a fused oneDNN kernel there
+        c = x.shape[1]
+        return F.conv2d(F.pad(x, (1, 1, 1, 1)), w_hwc.permute(2, 0, 1).unsqueeze(1), b, groups=c)
     y = _Depthwise3x3.apply(x, w_hwc.contiguous())
     return y if b is None else y + b.view(1, -1, 1, 1)
 

@@ -18,10 +18,11 @@ static float* dev_rand(size_t n, float scale, unsigned seed) {
 }
 int main(int argc, char** argv) {
   const int nb = argc > 1 ? atoi(argv[1]) : 512;
+  const int IH = argc > 2 ? atoi(argv[2]) : 32, IW = argc > 3 ? atoi(argv[3]) : IH;       // even sizes
   for (int cfg = 0; cfg < 4; ++cfg) {
     const int ci = cfg < 2 ? 32 : 64, co = cfg < 2 ? 64 : 32, tr = cfg & 1;
-    ConvGeom g{nb, 32, 32, ci, 16, 16, co, 5, 5, 2, 2, 1, 1};
-    const size_t nbig = (size_t)nb * 32 * 32 * ci, nsm = (size_t)nb * 16 * 16 * co;
+    ConvGeom g{nb, IH, IW, ci, IH / 2, IW / 2, co, 5, 5, 2, 2, 1, 1};
+    const size_t nbig = (size_t)nb * IH * IW * ci, nsm = (size_t)nb * (IH / 2) * (IW / 2) * co;
     float* big = dev_rand(nbig, 1.f, 1); float* small = dev_rand(nsm, 1.f, 2);
     float* w = dev_rand(25 * ci * co, 0.05f, 3); float* b = dev_rand(256, 0.1f, 4);
     float *o1, *o2; const size_t nout = tr ? nbig : nsm;
@@ -44,7 +45,7 @@ int main(int argc, char** argv) {
     hipMemcpy(h1.data(), o1, nout * 4, hipMemcpyDeviceToHost); hipMemcpy(h2.data(), o2, nout * 4, hipMemcpyDeviceToHost);
     double num = 0, den = 0, mx = 0;
     for (size_t i = 0; i < nout; ++i) { const double d = (double)h1[i] - h2[i]; num += d * d; den += (double)h1[i] * h1[i]; if (std::fabs(d) > mx) mx = std::fabs(d); }
-    const double gf = 2.0 * nb * 256 * co * 25 * ci / 1e9;
+    const double gf = 2.0 * nb * (IH / 2) * (IW / 2) * co * 25 * ci / 1e9;
     printf("B %d ci %d co %d T %d : f32-MFMA %.1f us (%.0f TF)  split %.1f us (%.0f TF)   rel diff %.2e max %.2e\n", nb, ci, co, tr,
            ms[0] * 50, gf / (ms[0] * 50e-6) / 1e3, ms[1] * 50, gf / (ms[1] * 50e-6) / 1e3, std::sqrt(num / den), mx);
     fflush(stdout);
