@@ -87,9 +87,11 @@ def test_engine_dp2_bf16_c64nb(tmp_path, overlap):
     ranks of 8 images sharing one GPU over gloo, single-message and two-phase exchange).  What data parallelism adds is
     exact -- the all-reduce sums float32 arenas -- so the replicas must stay bit-identical; against the float64 oracle
     with per-replica BatchNorm groups the bars are the bf16 class of tests/test_bf16_gpu.py (a 4-image replica: its
-    batch-2 bars): per tensor, the relative error of the applied UPDATE (Adagrad's first step is lr * g / sqrt(0.1 + g^2):
-    at most the gradient's relative error) <= 0.2 for weights, median <= 1.5e-2; metrics <= 2e-2; BatchNorm moving
-    statistics <= 2e-2."""
+    small-batch bars): per tensor, the relative error of the applied UPDATE (Adagrad's first step is lr * g / sqrt(0.1 + g^2):
+    at most the gradient's relative error).  Measured (8 images per replica): median 3.3e-2 .. 3.5e-2, 90th percentile 9e-2,
+    worst weight 0.24 (a squeeze-excite Dense behind a BatchNorm over 8 rows: the same tensors lead the single-GPU bf16
+    report at small batches), metrics 6e-4, BatchNorm moving statistics 1e-5.  Bars: median <= 7e-2, worst weight <= 0.5,
+    metrics <= 2e-2, statistics <= 2e-2 -- a dropped or doubled shard moves every one of them by O(1)."""
     import json
     import torch.multiprocessing as mp
     name, B, world = "c64nb", 16, 2
@@ -129,5 +131,5 @@ def test_engine_dp2_bf16_c64nb(tmp_path, overlap):
         json.dump(rep, f, indent=1)
     assert float(r0["count"]) == B
     print(json.dumps(rep))
-    assert rep["median"] <= 0.1 and rep["worst_weight"][1] <= 0.6, rep
+    assert rep["median"] <= 7e-2 and rep["worst_weight"][1] <= 0.5, rep
     assert rep["r_exp"] <= 2e-2 and rep["kl"] <= 2e-2 and rep["state"] <= 2e-2, rep
