@@ -247,6 +247,70 @@ int mvae_resnet_backward(int32_t device, const float* x, const float* x0, const 
                          const float* w1, const float* ws, float* dx, float* dw0, float* db0, float* dw1, float* db1,
                          float* dws, float* dbs, float* work, void* stream);
 
+/* ---- layer operators (the rest of the block library): the device operators from which the Python
+ *      facade assembles attention_block / self_attention_block (layer_blocks.py:654-783), attenuate_activation and the
+ *      excite / inhibit masks and block (:191-412), resnet_block with strides (:847-853) and the BatchNormalization variants
+ *      of resnet_block / mobilenetV2_block (:521-537, 884-886).  The reference composes Keras layers in Python; these are
+ *      the same layers as stateless device calls (NHWC float32 device memory, the caller's buffers, weights in the Keras
+ *      layouts).  Weight / bias gradients are ADDED to dw / db (zero them first).
+ *      conv2d:     y = [relu](conv_SAME(x, w) + b), w [kh,kw,C,F], TF SAME padding, strides (sh, sw); a Dense layer is the
+ *                  1x1 case on a [B,1,1,C] tensor.  backward takes dpre = the gradient at the PRE-activation output
+ *                  (mvae_activation_backward gives it) and writes dx (nullable), dw += , db += (db nullable).
+ *      activation: MVAE_LAYER_ACT_*; ATTENUATE = (tanh(param * x) + 1) / 2 (attenuate_activation, :191-198).  backward is
+ *                  written on the OUTPUT y: dx = dy * act'(y).
+ *      eltwise:    op 0 add, 1 subtract, 2 multiply.
+ *      scale_channels: keras Multiply([x [B,H,W,C], m [B,C]]): y = x * m[b,c]; dx = dy * m; dm[b,c] = sum_hw dy * x.
+ *      global_maxpool: GlobalMaxPool2D with the position of the (first) maximum; backward scatters dy there.
+ *      maxpool_same:   MaxPooling2D(pool (ph,pw), strides (sh,sw), "same"); idx = y * W + x of the window's first maximum.
+ *      batchnorm:  keras BatchNormalization over the rows of x [M,C]; training = batch statistics (biased variance),
+ *                  else the given moving statistics; mean / invstd [C] are outputs kept for the backward; batch_var nullable.
+ *                  backward: work >= 2 C floats.
+ *      attention_core (:716-728, as written): S[b,i,j] = sum_p theta[b,p,i] phi[b,p,j]; scores = softmax_j S [B,F,F];
+ *                  out[b,j,p] = sum_i scores[b,i,j] g[b,p,i], i.e. the [B,F,HW] buffer the reference then RESHAPES to
+ *                  [B,H,W,F]; F <= 64.  backward: dout in that same [B,F,HW] layout; work >= B F F floats. ---- */
+#define MVAE_LAYER_ACT_LINEAR 0
+#define MVAE_LAYER_ACT_RELU 1
+#define MVAE_LAYER_ACT_SIGMOID 2
+#define MVAE_LAYER_ACT_TANH 3
+#define MVAE_LAYER_ACT_ATTENUATE 4
+int mvae_conv2d_forward(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, const float* b,
+                        int32_t F, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t relu, float* y, void* stream);
+int mvae_conv2d_backward(int32_t device, const float* x, const float* dpre, int32_t B, int32_t H, int32_t W, int32_t C,
+                         const float* w, int32_t F, int32_t kh, int32_t kw, int32_t sh, int32_t sw, float* dx, float* dw, float* db,
+                         void* stream);
+/*      depthwise3x3: keras DepthwiseConv2D(3x3, strides 1, 'same', relu), w [3,3,C,1]; backward: work >= B H W C floats. */
+int mvae_depthwise3x3_forward(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w,
+                              const float* b, float* y, void* stream);
+int mvae_depthwise3x3_backward(int32_t device, const float* x, const float* y, const float* dy, int32_t B, int32_t H, int32_t W,
+                               int32_t C, const float* w, float* dx, float* dw, float* db, float* work, void* stream);
+int mvae_activation_forward(int32_t device, int32_t act, const float* x, float* y, int64_t n, float param, void* stream);
+int mvae_activation_backward(int32_t device, int32_t act, const float* y, const float* dy, float* dx, int64_t n, float param,
+                             void* stream);
+int mvae_eltwise(int32_t device, int32_t op, const float* a, const float* b, float* out, int64_t n, void* stream);
+int mvae_scale_channels_forward(int32_t device, const float* x, const float* m, float* y, int32_t B, int64_t HW, int32_t C,
+                                void* stream);
+int mvae_scale_channels_backward(int32_t device, const float* x, const float* m, const float* dy, float* dx, float* dm, int32_t B,
+                                 int64_t HW, int32_t C, void* stream);
+int mvae_global_maxpool_forward(int32_t device, const float* x, float* y, int32_t* idx, int32_t B, int64_t HW, int32_t C,
+                                void* stream);
+int mvae_global_maxpool_backward(int32_t device, const float* dy, const int32_t* idx, float* dx, int32_t B, int64_t HW, int32_t C,
+                                 void* stream);
+int mvae_maxpool_same_forward(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ph, int32_t pw,
+                              int32_t sh, int32_t sw, float* y, int32_t* idx, void* stream);
+int mvae_maxpool_same_backward(int32_t device, const float* dy, const int32_t* idx, int32_t B, int32_t H, int32_t W, int32_t C,
+                               int32_t ph, int32_t pw, int32_t sh, int32_t sw, float* dx, void* stream);
+int mvae_batchnorm_forward(int32_t device, const float* x, int64_t M, int32_t C, const float* gamma, const float* beta, float eps,
+                           int32_t training, const float* moving_mean, const float* moving_var, float* mean, float* invstd,
+                           float* batch_var, float* y, void* stream);
+int mvae_batchnorm_backward(int32_t device, const float* x, const float* dy, int64_t M, int32_t C, const float* gamma,
+                            const float* mean, const float* invstd, int32_t training, float* dx, float* dgamma, float* dbeta,
+                            float* work, void* stream);
+int mvae_attention_core_forward(int32_t device, const float* theta, const float* phi, const float* g, int32_t B, int64_t HW,
+                                int32_t F, float* scores, float* out, void* stream);
+int mvae_attention_core_backward(int32_t device, const float* theta, const float* phi, const float* g, const float* scores,
+                                 const float* dout, int32_t B, int64_t HW, int32_t F, float* dtheta, float* dphi, float* dg,
+                                 float* work, void* stream);
+
 /* ---- diagnostics (process-global): per-launch HIP-event timing on the launch stream, used by bench.py for
  *      the per-kernel roofline line.  report writes a JSON object {tag: {count, ms, bytes, flops}} (algorithmic
  *      bytes / flops summed over the launches), returns its length, and clears the records; it synchronises. ---- */

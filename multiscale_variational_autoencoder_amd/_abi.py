@@ -96,6 +96,23 @@ SYMBOLS = {
     "mvae_mnv2_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p] * 11 + [C.c_void_p]),
     "mvae_resnet_forward": (C.c_int, [C.c_int32, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p] * 9 + [C.c_void_p]),
     "mvae_resnet_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 8 + [C.c_void_p] * 11 + [C.c_void_p]),
+    "mvae_conv2d_forward": (C.c_int, [C.c_int32, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p] * 2 + [C.c_int32] * 6 + [C.c_void_p] * 2),
+    "mvae_conv2d_backward": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] * 4),
+    "mvae_depthwise3x3_forward": (C.c_int, [C.c_int32, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p] * 4),
+    "mvae_depthwise3x3_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 6),
+    "mvae_activation_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "mvae_activation_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "mvae_eltwise": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mvae_scale_channels_forward": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "mvae_scale_channels_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 5 + [C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "mvae_global_maxpool_forward": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "mvae_global_maxpool_backward": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "mvae_maxpool_same_forward": (C.c_int, [C.c_int32, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p] * 3),
+    "mvae_maxpool_same_backward": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p] * 2),
+    "mvae_batchnorm_forward": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int32] + [C.c_void_p] * 7),
+    "mvae_batchnorm_backward": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 5),
+    "mvae_attention_core_forward": (C.c_int, [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 3),
+    "mvae_attention_core_backward": (C.c_int, [C.c_int32] + [C.c_void_p] * 5 + [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 5),
     "mvae_profile_enable": (C.c_int, [C.c_int32]),
     "mvae_profile_report": (C.c_int64, [C.c_char_p, C.c_int64]),
     "mvae_tensor_lookup": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),

@@ -278,6 +278,32 @@ bool launch_dense_wgrad_dec(const float* z, const float* dy, float* dW, float* d
                             bool bf = false);
 void launch_add_vec2(float* o0, const float* a0, float* o1, const float* a1, int n, hipStream_t s);
 
+// ---- operators of the remaining block library (kernels_layers.hip; include/mvae_hip.h: MVAE_LAYER_ACT_*) ----
+enum { LAYER_ACT_LINEAR = 0, LAYER_ACT_RELU = 1, LAYER_ACT_SIGMOID = 2, LAYER_ACT_TANH = 3, LAYER_ACT_ATTENUATE = 4 };
+void launch_act_fwd(int act, const float* x, float* y, int64_t n, float m, hipStream_t s);
+void launch_act_bwd(int act, const float* y, const float* dy, float* dx, int64_t n, float m, hipStream_t s);   // dx = dy * act'(y)
+void launch_eltwise(int op, const float* a, const float* b, float* out, int64_t n, hipStream_t s);             // 0 +, 1 -, 2 *
+void launch_scale_channels(const float* x, const float* m, float* y, int B, int64_t HW, int C, hipStream_t s);  // y = x * m[b, c]
+void launch_scale_channels_bwd_m(const float* x, const float* dy, float* dm, int B, int64_t HW, int C, hipStream_t s);
+void launch_gmax_fwd(const float* x, float* y, int* idx, int B, int64_t HW, int C, hipStream_t s);
+void launch_gmax_bwd(const float* dy, const int* idx, float* dx, int B, int64_t HW, int C, hipStream_t s);
+void launch_maxpool_fwd(const float* x, float* y, int* idx, int B, int H, int W, int C, int OH, int OW, int ph, int pw, int sh,
+                        int sw, int pt, int pl, hipStream_t s);
+void launch_maxpool_bwd(const float* dy, const int* idx, float* dx, int B, int H, int W, int C, int OH, int OW, int ph, int pw,
+                        int sh, int sw, int pt, int pl, hipStream_t s);
+void launch_bn_rows_stats(const float* x, float* mean, float* invstd, float* var_out, int64_t M, int C, float eps, hipStream_t s);
+void launch_bn_rows_from_moving(const float* mm, const float* mv, float* mean, float* invstd, int C, float eps, hipStream_t s);
+void launch_bn_rows_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y,
+                          int64_t M, int C, hipStream_t s);
+void launch_bn_rows_bwd_sums(const float* x, const float* dy, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                             int64_t M, int C, hipStream_t s);                       // dgamma / dbeta += this launch's column sums
+void launch_bn_rows_bwd_apply(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                              const float* sum_dy, const float* sum_dyx, float* dx, int training, int64_t M, int C, hipStream_t s);
+bool launch_attention_core_fwd(const float* theta, const float* phi, const float* g, float* scores, float* out, int B, int64_t HW,
+                               int F, hipStream_t s);
+bool launch_attention_core_bwd(const float* theta, const float* phi, const float* g, const float* scores, const float* dout,
+                               float* dtheta, float* dphi, float* dg, float* work, int B, int64_t HW, int F, hipStream_t s);
+
 // ---- glue of the stand-alone block library (kernels_blocks.hip) ----
 void launch_relu_bwd(const float* dy, const float* y, float* out, int64_t n, hipStream_t s);       // out = dy * (y > 0)
 void launch_relu_add(float* y, const float* r, bool relu, int64_t n, hipStream_t s);             // y = [relu](y) (+ r)

@@ -285,6 +285,14 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float* __restrict__ 
     }
   }
 }
+__global__ void __launch_bounds__(256) k_bn_from_moving(const float* __restrict__ mm, const float* __restrict__ mv,
+                                                        float* __restrict__ mean, float* __restrict__ invstd, int C, float eps) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) { mean[c] = mm[c]; invstd[c] = rsqrtf(mv[c] + eps); }
+}
+void launch_bn_rows_from_moving(const float* mm, const float* mv, float* mean, float* invstd, int C, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(k_bn_from_moving, dim3((C + 255) / 256), dim3(256), 0, s, mm, mv, mean, invstd, C, eps);
+}
 void launch_bn_rows_stats(const float* x, float* mean, float* invstd, float* var_out, int64_t M, int C, float eps, hipStream_t s) {
   hipLaunchKernelGGL(k_bn_stats, dim3((C + 63) / 64), dim3(256), 0, s, x, mean, invstd, var_out, M, C, eps);
 }

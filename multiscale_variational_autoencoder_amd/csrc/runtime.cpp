@@ -1621,6 +1621,7 @@ int mvae_train_step(mvae_handle* h, const mvae_step_io* io, float r_factor, floa
 // from the ROCm installation otherwise.  SURVEY 8(b) / 8(e): one ncclAllReduce(sum, float32) over the reduce arena
 // [gradients | BatchNorm batch statistics | metrics] per step on the caller's stream, then the identical clipnorm + Adagrad
 // on every rank with grad_scale = 1 / nranks.
+extern "C++" {
 namespace {
 
 struct RcclId { char internal[MVAE_COMM_ID_BYTES]; };           // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
@@ -1663,6 +1664,7 @@ RcclApi& rccl() {
 }
 
 }  // namespace
+}  // extern "C++"
 
 int mvae_comm_unique_id(char id[MVAE_COMM_ID_BYTES]) {
   if (!id) return MVAE_E_INVALID;

@@ -390,8 +390,11 @@ def mobilenetV2_block(input_dims, filters=32, dropout_ratio=0.0, use_batchnorm=F
         raise ValueError("Filters should be > 0")
     if dropout_ratio is not None and (dropout_ratio > 1.0 or dropout_ratio < 0.0):
         raise ValueError("Dropout ration must be [0, 1]")
-    if use_batchnorm or (dropout_ratio or 0.0) > 0.0 or initializer != "glorot_normal":
-        raise ValueError("the HIP path implements the reference's defaults (no BatchNorm, no dropout, glorot_normal)")
+    if (dropout_ratio or 0.0) > 0.0 or initializer != "glorot_normal":
+        raise ValueError("the HIP path implements dropout_ratio 0 and glorot_normal (the reference's defaults)")
+    if use_batchnorm:                       # :521-537: BatchNormalization behind the depthwise and the second 1x1 convolution
+        from .layer_ops import MobileNetV2BlockBN
+        return MobileNetV2BlockBN(input_dims, filters, name=prefix)
     return MobileNetV2Block(input_dims, filters, name=prefix)
 
 
@@ -404,6 +407,86 @@ def resnet_block(input_dims, filters=32, kernel_size=(3, 3), strides=(1, 1), act
         raise ValueError("Filters should be > 0")
     if dropout_ratio is not None and (dropout_ratio > 1.0 or dropout_ratio < 0.0):
         raise ValueError("Dropout ration must be [0, 1]")
-    if use_batchnorm or (dropout_ratio or 0.0) > 0.0 or initializer != "glorot_normal":
-        raise ValueError("the HIP path implements the reference's defaults (no BatchNorm, no dropout, glorot_normal)")
+    if (dropout_ratio or 0.0) > 0.0 or initializer != "glorot_normal":
+        raise ValueError("the HIP path implements dropout_ratio 0 and glorot_normal (the reference's defaults)")
+    if use_batchnorm or tuple(strides) != (1, 1) or activation not in ("relu", "linear"):
+        # :847-853 (MaxPooling2D skip path of a strided block), :884-886 (BatchNormalization): the layer-operator composition
+        from .layer_ops import ResnetBlockGeneral
+        return ResnetBlockGeneral(input_dims, filters, kernel_size, strides, activation, use_batchnorm, name=prefix)
     return ResnetBlock(input_dims, filters, kernel_size, strides, activation, name=prefix)
+
+
+# ---- the rest of the block library (layer_blocks.py:191-412, 654-783): assembled from the layer operators (layer_ops.py) ----
+DEFAULT_ATTENUATION_MULTIPLIER = 4.0      # layer_blocks.py:14
+
+
+def attenuate_activation(input_layer, multiplier=DEFAULT_ATTENUATION_MULTIPLIER):
+    """layer_blocks.py:191-198 applied to an array on the device."""
+    from .layer_ops import attenuate_activation as _att
+    return _att(input_layer, multiplier)
+
+
+def _dims4(input_dims, what="works only on 4d tensors"):
+    if input_dims is None:
+        raise ValueError("input_layer cannot be empty")
+    if len(input_dims) != 3:                      # (H, W, C): the batch axis is implicit
+        raise ValueError(what)
+    return tuple(int(d) for d in input_dims)
+
+
+def attention_block(input_dims, filters=32, kernel_size=(1, 1), activation="linear", initializer="glorot_normal", regularizer=None,
+                    prefix="attention_"):
+    """layer_blocks.py:654-728 with the reference's argument checks; the input is given by its shape (H, W, C)."""
+    from .layer_ops import AttentionBlock
+    dims = _dims4(input_dims, "only supports 4d tensors")
+    if filters <= 0:
+        raise ValueError("Filters should be > 0")
+    if initializer != "glorot_normal":
+        raise ValueError("the HIP path implements glorot_normal (the reference's default)")
+    return AttentionBlock(dims, filters, kernel_size, activation, name=prefix)
+
+
+def self_attention_block(input_dims, filters=32, kernel_size=(1, 1), activation="linear", initializer="glorot_normal",
+                         regularizer=None, prefix="self_attention_", channels_index=3):
+    """layer_blocks.py:734-783."""
+    from .layer_ops import SelfAttentionBlock
+    dims = _dims4(input_dims, "only supports 4d tensors")
+    if filters <= 0:
+        raise ValueError("Filters should be > 0")
+    if initializer != "glorot_normal":
+        raise ValueError("the HIP path implements glorot_normal (the reference's default)")
+    return SelfAttentionBlock(dims, filters, kernel_size, activation, name=prefix)
+
+
+def excite_inhibit_spatial_mask_block(input_dims, filters=32, kernel_size=(3, 3), flatten=False, add_batchnorm=False,
+                                      first_level_activation="relu", second_level_activation="sigmoid",
+                                      multiplier=DEFAULT_ATTENUATION_MULTIPLIER, kernel_regularizer="l1",
+                                      kernel_initializer="glorot_normal", channels_index=3):
+    """layer_blocks.py:204-271."""
+    from .layer_ops import ExciteInhibitSpatialMask
+    dims = _dims4(input_dims)
+    if add_batchnorm or kernel_initializer != "glorot_normal":
+        raise ValueError("the HIP path implements add_batchnorm=False and glorot_normal (the reference's defaults)")
+    return ExciteInhibitSpatialMask(dims, filters, kernel_size, flatten, first_level_activation, second_level_activation, multiplier)
+
+
+def excite_inhibit_channel_mask_block(input_dims, filters=32, kernel_size=(3, 3), shared=True, add_batchnorm=False,
+                                      first_level_activation="linear", second_level_activation="sigmoid",
+                                      multiplier=DEFAULT_ATTENUATION_MULTIPLIER, kernel_regularizer="l1",
+                                      kernel_initializer="glorot_normal", channels_index=3):
+    """layer_blocks.py:277-350."""
+    from .layer_ops import ExciteInhibitChannelMask
+    dims = _dims4(input_dims)
+    if add_batchnorm or kernel_initializer != "glorot_normal":
+        raise ValueError("the HIP path implements add_batchnorm=False and glorot_normal (the reference's defaults)")
+    return ExciteInhibitChannelMask(dims, filters, kernel_size, shared, first_level_activation, second_level_activation, multiplier)
+
+
+def excite_inhibit_block(input_dims, filters=32, kernel_size=(3, 3), kernel_regularizer="l1", kernel_initializer="glorot_normal",
+                         channels_index=3):
+    """layer_blocks.py:356-412."""
+    from .layer_ops import ExciteInhibitBlock
+    dims = _dims4(input_dims)
+    if kernel_initializer != "glorot_normal":
+        raise ValueError("the HIP path implements glorot_normal (the reference's default)")
+    return ExciteInhibitBlock(dims, filters, kernel_size)
