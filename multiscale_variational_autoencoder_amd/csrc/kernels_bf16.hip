@@ -849,6 +849,198 @@ __global__ void __launch_bounds__(NTHR) k16_taps(const bf16_t* __restrict__ in, 
 }
 
 // =================================================================================================
+// T-form with the four sub-pixel phases of a stride-2 5 x 5 transposed convolution MERGED (round 4; the bf16 counterpart of
+// k_convt_merged_s, kernels_split.hip).  Output pixel (2 cy + py, 2 cx + px) sums the taps kh = py + 1 - 2 dy,
+// kw = px + 1 - 2 dx over the input pixels (cy + dy, cx + dx), dy, dx in {-1, 0, 1}: the 25 taps of the four phases read
+// only NINE distinct input offsets.  k16_taps<.., TFORM> runs one phase per blockIdx.y and gathers its 32 pixels once per
+// tap (25 gathers, 25 LDS tile writes and 25 x KK fragment reads per 4 x 32 output pixels); here a wave's tile is 32
+// input-grid positions and all four phases of them: 9 gathers, 9 tile writes, 9 x KK fragment reads, 25 x KK x NT MFMAs
+// into acc[phase].  All 25 weight slices stay in LDS as bf16 ([tap][n][k], 100 KB), like the F-form kernel.
+// Requires KH = KW = 5, SH = SW = 2, PT = PL = 1, IH = 2 OH, IW = 2 OW.
+// =================================================================================================
+namespace tm16 {
+__device__ __forceinline__ constexpr int o_dy(int oi) { return oi == 0 ? 0 : oi == 1 ? 0 : oi == 2 ? -1 : oi == 3 ? -1 : oi == 4 ? 1 : oi == 5 ? 1 : oi == 6 ? 0 : oi == 7 ? -1 : 1; }
+__device__ __forceinline__ constexpr int o_dx(int oi) { return oi == 0 ? 0 : oi == 1 ? -1 : oi == 2 ? 0 : oi == 3 ? -1 : oi == 4 ? 0 : oi == 5 ? -1 : oi == 6 ? 1 : oi == 7 ? 1 : 1; }
+__device__ __forceinline__ constexpr int o_ny(int oi) { return o_dy(oi) == 1 ? 1 : 2; }
+__device__ __forceinline__ constexpr int o_nx(int oi) { return o_dx(oi) == 1 ? 1 : 2; }
+}  // namespace tm16
+
+template <int KC, int NC, int NTHR, bool CHAIN = false>
+__global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ in, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, bf16_t* __restrict__ out, ConvGeom g,
+                                                   unsigned in_bytes, int tiles_per_wave, const float* __restrict__ W2,
+                                                   const float* __restrict__ bias2, bf16_t* __restrict__ out2) {
+  constexpr int NT = NC / 32, KK = KC / 16;
+  static_assert(!CHAIN || NC == 64, "chained conv0: 64 output channels");
+  __shared__ __attribute__((aligned(16))) char sW2[CHAIN ? 8 * 64 * 16 + 64 * 4 : 16];
+  u32x4* wfl2 = reinterpret_cast<u32x4*>(sW2);
+  float* b2s = reinterpret_cast<float*>(sW2 + 8 * 64 * 16);
+  if constexpr (CHAIN) {
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x;
+      bf16x8 w2[2][4];
+      load_wfrags<64, 64, false>(W2, l & 31, l >> 5, w2);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wfl2[(nt * 4 + kk) * 64 + l] = __builtin_bit_cast(u32x4, w2[nt][kk]);
+      b2s[l] = bias2 ? bias2[l] : 0.f;
+    }
+  }
+  constexpr int CPP = KC / 8, LX = KC / 16;
+  __shared__ __attribute__((aligned(16))) char sW[25 * NC * KC * 2];
+  __shared__ __attribute__((aligned(16))) char sA[(NTHR / 64) * 32 * KC * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  char* myA = sA + wave * (32 * KC * 2);
+  const int CH = g.OH, CW = g.OW;
+  const unsigned Mc = (unsigned)(g.B * CH * CW);
+  // ---- all 25 weight slices -> LDS, bf16, T layout [tap][n][k] (W[tap][n = ci][k = co]), chunks XOR-swizzled as k16_taps
+  for (int idx = threadIdx.x; idx < 25 * NC * KC; idx += NTHR) {
+    const int tap = idx / (NC * KC), rem = idx % (NC * KC);
+    const int n = rem / KC, k = rem % KC;
+    const float v = W[idx];
+    const int off = tap * NC * KC * 2 + n * KC * 2 + (((k >> 3) ^ ((KC == 32 ? n >> 1 : n) & (KC / 8 - 1))) << 4) + (k & 7) * 2;
+    *reinterpret_cast<uint16_t*>(sW + off) = (uint16_t)(pack_bf16(v, 0.f) & 0xFFFFu);
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(in), 0, (int)in_bytes, 0x00020000);
+  const bool pow2 = (CW & (CW - 1)) == 0 && (CH & (CH - 1)) == 0;
+  const int lgw = 31 - __builtin_clz((unsigned)CW), lgh = 31 - __builtin_clz((unsigned)CH);
+  auto split = [&](unsigned p, int& cx, int& cy, int& b) {
+    if (pow2) { cx = (int)(p & (unsigned)(CW - 1)); cy = (int)((p >> lgw) & (unsigned)(CH - 1)); b = (int)(p >> (lgw + lgh)); }
+    else { cx = (int)(p % (unsigned)CW); const unsigned q = p / (unsigned)CW; cy = (int)(q % (unsigned)CH); b = (int)(q / (unsigned)CH); }
+  };
+  const unsigned wtile0 = ((unsigned)blockIdx.x * (unsigned)(NTHR / 64) + wave) * (unsigned)tiles_per_wave;
+  for (int ti = 0; ti < tiles_per_wave; ++ti) {
+    const unsigned p0 = (wtile0 + ti) * 32u;
+    if (p0 >= Mc) break;                                       // wave-uniform
+    unsigned base[LX], inv[LX];
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+      const unsigned p = p0 + (unsigned)(j * (64 / CPP) + lane / CPP);
+      int cx, cy, b;
+      split(p < Mc ? p : 0u, cx, cy, b);
+      base[j] = (unsigned)(((b * CH + cy) * CW + cx) * KC + (lane % CPP) * 8) * 2u;
+      unsigned m = p < Mc ? 0u : 0x77u;                        // bit dy + 1 / bit 4 + dx + 1: the offset leaves the image
+      if (cy == 0) m |= 1u;
+      if (cy == CH - 1) m |= 4u;
+      if (cx == 0) m |= 0x10u;
+      if (cx == CW - 1) m |= 0x40u;
+      inv[j] = m;
+    }
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[ph][nt] = zero16();
+    u32x4 xc[LX], xn[LX];
+    auto fetch = [&](int oi, u32x4 (&dst)[LX]) {
+      const int dy = tm16::o_dy(oi), dx = tm16::o_dx(oi);
+      const unsigned delta = (unsigned)((dy * CW + dx) * KC * 2);
+      const unsigned sel = (1u << (dy + 1)) | (0x10u << (dx + 1));
+#pragma unroll
+      for (int j = 0; j < LX; ++j)
+        dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (inv[j] & sel) ? 0x80000000u : base[j] + delta, 0, 0);
+    };
+    fetch(0, xc);
+#pragma unroll
+    for (int oi = 0; oi < 9; ++oi) {
+      if (oi + 1 < 9) fetch(oi + 1, xn);                        // next offset's rows in flight under this offset's taps
+      WAVE_LDS_SYNC16();                                         // the previous offset's fragment reads are done
+#pragma unroll
+      for (int j = 0; j < LX; ++j) {
+        const int c = j * 64 + lane;
+        *reinterpret_cast<u32x4*>(myA + tile_off<KC>(c / CPP, c % CPP)) = xc[j];
+      }
+      WAVE_LDS_SYNC16();
+      bf16x8 xb[KK];
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) xb[kk] = frag_rows<KC>(myA, r, h, kk);
+      constexpr int dummy = 0; (void)dummy;
+#pragma unroll
+      for (int jy = 0; jy < tm16::o_ny(oi); ++jy)
+#pragma unroll
+        for (int jx = 0; jx < tm16::o_nx(oi); ++jx) {
+          const int py = tm16::o_dy(oi) == 1 ? 1 : jy, px = tm16::o_dx(oi) == 1 ? 1 : jx;
+          const int kh = py + 1 - 2 * tm16::o_dy(oi), kw = px + 1 - 2 * tm16::o_dx(oi);
+          const char* wt = sW + (kh * 5 + kw) * NC * KC * 2;
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int n = nt * 32 + r;
+              const bf16x8 wa = as_frag(*reinterpret_cast<const u32x4*>(wt + n * KC * 2 + (((2 * kk + h) ^ ((KC == 32 ? n >> 1 : n) & (KC / 8 - 1))) << 4)));
+              acc[py * 2 + px][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[kk], acc[py * 2 + px][nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+      for (int j = 0; j < LX; ++j) xc[j] = xn[j];
+    }
+    // ---- epilogue per phase: bias, pack, 16-byte stores (as k16_taps)
+    const unsigned p = p0 + r;
+    int cx, cy, b;
+    split(p < Mc ? p : 0u, cx, cy, b);
+    const int64_t opix00 = (int64_t)(b * g.IH + cy * 2) * g.IW + cx * 2;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      const int64_t opix = opix00 + (ph >> 1) * g.IW + (ph & 1);
+      u32x4 och[CHAIN ? 4 : 1];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        uint2 pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+          if (bias) bq = *reinterpret_cast<const f32x4*>(bias + nt * 32 + 8 * q + 4 * h);
+          f32x4 v = {acc[ph][nt][4 * q] + bq[0], acc[ph][nt][4 * q + 1] + bq[1], acc[ph][nt][4 * q + 2] + bq[2],
+                     acc[ph][nt][4 * q + 3] + bq[3]};
+          pk[q] = pack4(v);
+        }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          uint2 a = pk[2 * pp], bb = pk[2 * pp + 1];
+          auto s0 = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
+          const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+          if constexpr (CHAIN) och[2 * nt + pp] = o;
+          if (p < Mc) *reinterpret_cast<u32x4*>(out + opix * NC + nt * 32 + 16 * pp + 8 * h) = o;
+        }
+      }
+      if constexpr (CHAIN) {
+        f32x16 a2[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) a2[nt] = zero16();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            a2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wfl2[(nt * 4 + kk) * 64 + lane]), as_frag(och[kk]), a2[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          uint2 pk[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {a2[nt][4 * q], a2[nt][4 * q + 1], a2[nt][4 * q + 2], a2[nt][4 * q + 3]};
+            v += *reinterpret_cast<const f32x4*>(b2s + nt * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            pk[q] = pack4(v);
+          }
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) {
+            uint2 a = pk[2 * pp], bb = pk[2 * pp + 1];
+            auto s0 = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
+            if (p < Mc) *reinterpret_cast<u32x4*>(out2 + opix * 64 + nt * 32 + 16 * pp + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          }
+        }
+      }
+    }
+  }
+}
+
+// =================================================================================================
 // Weight gradient of a strided SAME convolution (F-form coordinates), bf16 storage:
 //   dW[tap][ci][co] += sum_m big[gather(m, tap)][ci] * small[m][co] ;  db[co] += sum_m small[m][co]
 // One block per (row chunk, kernel row kh) as k_wgrad_taprow: the TG = KW taps of the row share the staged `small` tile
@@ -1387,6 +1579,29 @@ bool launch16_taps(bool transposed, const void* in, const float* w, const float*
   hipLaunchKernelGGL((k16_taps<A, B_, TF, MT, 64 * NW>), dim3(gx, classes), dim3(64 * NW), 0, s,                      \
                      (const bf16_t*)in, w, bias, (bf16_t*)out, g, in_bytes, tpw, nullptr, nullptr, nullptr)
   if (transposed && (((g.KH + g.SH - 1) / g.SH) * ((g.KW + g.SW - 1) / g.SW) > 9)) return false;   // taps per phase
+  // the four sub-pixel phases merged in one block (k16_taps_tm): 5 x 5, stride 2, even sizes, SAME padding
+  static const bool merged_on = [] { const char* e = getenv("MVAE_CONVT_MERGED16"); return e ? atoi(e) != 0 : true; }();
+  if (transposed && merged_on && g.KH == 5 && g.KW == 5 && g.SH == 2 && g.SW == 2 && g.PT == 1 && g.PL == 1 && g.IH == 2 * g.OH &&
+      g.IW == 2 * g.OW) {
+    static const bool chain_m = [] { const char* e = getenv("MVAE_FUSE_PW_CHAIN"); return e ? atoi(e) != 0 : true; }();
+    const int64_t Mm = (int64_t)g.B * g.OH * g.OW, tiles_m = (Mm + 31) / 32;
+    int64_t wv = (int64_t)8 * cus16();                                 // one 8-wave block per CU (100 KB of weight slices)
+    if (wv > tiles_m) wv = tiles_m;
+    const int tpw_m = (int)((tiles_m + wv - 1) / wv);
+    const unsigned gxm = (unsigned)(((tiles_m + tpw_m - 1) / tpw_m + 7) / 8);
+    if (KC == 32 && NC == 64 && w2 && out2 && chain_m) {
+      hipLaunchKernelGGL((k16_taps_tm<32, 64, 512, true>), dim3(gxm), dim3(512), 0, s, (const bf16_t*)in, w, bias, (bf16_t*)out, g,
+                         in_bytes, tpw_m, w2, bias2, (bf16_t*)out2);
+      if (chained) *chained = true;
+    } else if (KC == 32 && NC == 64) {
+      hipLaunchKernelGGL((k16_taps_tm<32, 64, 512, false>), dim3(gxm), dim3(512), 0, s, (const bf16_t*)in, w, bias, (bf16_t*)out, g,
+                         in_bytes, tpw_m, nullptr, nullptr, nullptr);
+    } else {
+      hipLaunchKernelGGL((k16_taps_tm<64, 32, 512, false>), dim3(gxm), dim3(512), 0, s, (const bf16_t*)in, w, bias, (bf16_t*)out, g,
+                         in_bytes, tpw_m, nullptr, nullptr, nullptr);
+    }
+    return true;
+  }
   static const bool chain_on = [] { const char* e = getenv("MVAE_FUSE_PW_CHAIN"); return e ? atoi(e) != 0 : true; }();
   if (KC == 32 && NC == 64 && transposed && w2 && out2 && chain_on) {
     hipLaunchKernelGGL((k16_taps<32, 64, true, 9, 512, true>), dim3(gx, classes), dim3(512), 0, s, (const bf16_t*)in, w, bias,

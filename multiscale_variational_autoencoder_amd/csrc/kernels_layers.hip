@@ -26,7 +26,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float act_fwd(int act, float x, float m) {
   switch (act) {
     case LAYER_ACT_RELU: return x > 0.f ? x : 0.f;
-    case LAYER_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+    case LAYER_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
     case LAYER_ACT_TANH: return tanhf(x);
     case LAYER_ACT_ATTENUATE: return 0.5f * (tanhf(m * x) + 1.f);
     default: return x;
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) k_attn_softmax(float* __restrict__ S, con
     float v = l < F ? s[l] : -INFINITY, m = v;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    const float e = l < F ? __expf(v - m) : 0.f;
+    const float e = l < F ? expf(v - m) : 0.f;
     const float z = wave_sum(e);
     if (l < F) s[l] = e / z;
   } else {

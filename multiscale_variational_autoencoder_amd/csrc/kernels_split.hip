@@ -484,6 +484,208 @@ k_convt_merged_s(const float* __restrict__ in, const char* __restrict__ Wp, cons
   ConvTMergedS<KC, NC, NW>::run(in, Wp, bias, out, g, in_bytes, out_bytes, sW, sA[wave], p0, Mc);
 }
 
+// =================================================================================================
+// F-form (5 x 5, stride 2, SAME) with the input rows of a KERNEL ROW staged in LDS once (round 4).
+// k_conv_taps_s<.., TFORM = false> gathers a wave's 32 input pixels once per TAP: 25 gathers of 32 pixels and 25 three-plane
+// splits per tile, and every input pixel crosses the fabric ~6 times because the 25 taps' footprint of the blocks resident on
+// an XCD does not fit its L2 (PMC, round 3: 352 MB of fabric reads for a 151 MB launch; the kernel ran at the ~30 GB/s per CU
+// of gathers served behind L2, MI355X_MICROARCH.md "Indexed rows").  Here a wave's tile is still 32 consecutive output pixels
+// = R = 32 / COLS output rows of COLS = min(32, OW) columns, but per kernel row kh it loads the R input row segments those
+// pixels read through the five kw taps -- 2 COLS + 3 pixels each, e.g. 2 x 35 instead of 5 x 32 pixels at OW = 16 -- splits
+// them ONCE into the three bf16 planes and keeps them in its LDS region; the five taps of the row then read their A
+// fragments from LDS at pixel 2 c + kw.  Even and odd segment pixels are stored apart (row index = ((q & 1) HALF +
+// (q >> 1)) R + j), so the 32 lanes of a fragment read walk rows at a fixed stride whatever kw is.
+// Gathered bytes per tile: 5 x 70 instead of 25 x 32 pixels (2.3x fewer), split work likewise.
+// =================================================================================================
+template <int KC, int NC, int COLS, int NW>
+struct ConvFRowsS {
+  static constexpr int NT = NC / 32, KK = KC / 16;
+  static constexpr int CPP = KC / 4, PPI = 64 / CPP;                 // lanes per pixel, pixels per load instruction
+  static constexpr int R = 32 / COLS, SEG = 2 * COLS + 3, HALF = COLS + 2, NPX = R * SEG;
+  static constexpr int NL = (NPX + PPI - 1) / PPI;                   // load slots per lane and kernel row
+  static constexpr int PLANE_W = NC * KC * 2, TAPB = 3 * PLANE_W;
+  static constexpr int PLANE_A = ((NPX + 7) / 8 * 8) * KC * 2;       // one bf16 plane of the staged rows
+  static constexpr int NTHR = 64 * NW;
+  static constexpr int WLD = (TAPB + NTHR * 16 - 1) / (NTHR * 16);
+  static constexpr bool WRAG = TAPB % (NTHR * 16) != 0;
+  static constexpr int PF = 2;
+
+  static __device__ __forceinline__ void run(const float* __restrict__ in, const char* __restrict__ Wp,
+                                             const float* __restrict__ bias, float* __restrict__ out, const ConvGeom& g,
+                                             unsigned in_bytes, unsigned out_bytes, char (*sW)[TAPB], char* myA, unsigned p0,
+                                             unsigned Mc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int lp = lane / CPP, ch = lane % CPP;
+    const int CW = g.OW, CH = g.OH;
+    const unsigned ptile = p0 + wave * 32;
+    // ---- staging slots: pixel s = u PPI + lp of the R x SEG staged pixels -> (output row j, segment column q)
+    unsigned base[NL];                 // byte offset of (input row of kernel row 0, segment column q, channel chunk)
+    unsigned rmask[NL];                // bit kh: that kernel row's input row is outside the image (or the slot is unused)
+    int lds_o[NL];                     // byte offset of the slot's 8-byte piece inside a plane
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int sidx = u * PPI + lp;
+      const int j = sidx / SEG, q = sidx - j * SEG;
+      const unsigned pj = ptile + (unsigned)(j * COLS);
+      const bool live = sidx < NPX && pj < Mc;
+      const unsigned pp = live ? pj : 0u;
+      const int ox0 = (int)(pp % (unsigned)CW);
+      const unsigned t2 = pp / (unsigned)CW;
+      const int oy = (int)(t2 % (unsigned)CH), b = (int)(t2 / (unsigned)CH);
+      const int x = ox0 * 2 - g.PL + q, y0 = oy * 2 - g.PT;
+      unsigned m = (live && (unsigned)x < (unsigned)g.IW) ? 0u : 0x1Fu;
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh)
+        if ((unsigned)(y0 + kh) >= (unsigned)g.IH) m |= 1u << kh;
+      rmask[u] = m;
+      base[u] = (unsigned)(((b * g.IH + y0) * g.IW + x) * KC + ch * 4) * 4u;      // (wraps for y0 < 0: only used unmasked)
+      const int rho = ((q & 1) * HALF + (q >> 1)) * R + j;      // output row j minor: see the fragment rows below
+      lds_o[u] = tile_off<KC>(rho, ch >> 1) + (ch & 1) * 8;
+    }
+    const unsigned row_bytes = (unsigned)(g.IW * KC * 4);
+    // ---- fragment rows: output pixel i = (j, c) reads LDS row ((kw & 1) HALF + c + (kw >> 1)) R + j.  With the output row as
+    // the MINOR index the 16 lanes of a ds_read_b128 group ({0-3, 12-15, 20-27}, ...) hit 16 rows that are distinct mod 16 for
+    // R = 1, 2, 4, 8: no bank conflicts (with j major, rows 39.. of the second output row collided with rows 12.. of the first)
+    const int rho0 = (i % COLS) * R + (i / COLS);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00020000);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    u32x4 wreg[PF][WLD], areg[NL];
+    auto fetch_w = [&](int t, int slot) {
+      const u32x4* wt = reinterpret_cast<const u32x4*>(Wp + (size_t)t * TAPB);          // t = kh * 5 + kw
+#pragma unroll
+      for (int u = 0; u < WLD; ++u) {
+        const int idx = (int)threadIdx.x + u * NTHR;
+        wreg[slot][u] = wt[(WRAG && idx * 16 >= TAPB) ? (int)threadIdx.x : idx];
+      }
+    };
+    auto fetch_a = [&](int kh) {
+#pragma unroll
+      for (int u = 0; u < NL; ++u) {
+        const unsigned off = (rmask[u] >> kh) & 1u ? 0x80000000u : base[u] + (unsigned)kh * row_bytes;
+        areg[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+      }
+    };
+    auto stage_a = [&]() {               // split + store slot by slot (the region's readers -- this wave -- are done)
+#pragma unroll
+      for (int u = 0; u < NL; ++u) {
+        u32x2 p1, p2, p3;
+        split4(areg[u], p1, p2, p3);
+        if (u * PPI + lp < NPX) {
+          *reinterpret_cast<u32x2*>(myA + lds_o[u]) = p1;
+          *reinterpret_cast<u32x2*>(myA + PLANE_A + lds_o[u]) = p2;
+          *reinterpret_cast<u32x2*>(myA + 2 * PLANE_A + lds_o[u]) = p3;
+        }
+      }
+    };
+    auto store_w = [&](int slot, int buf) {
+#pragma unroll
+      for (int u = 0; u < WLD; ++u) {
+        const int idx = (int)threadIdx.x + u * NTHR;
+        if (!WRAG || idx * 16 < TAPB) reinterpret_cast<u32x4*>(sW[buf])[idx] = wreg[slot][u];
+      }
+    };
+    fetch_a(0);
+#pragma unroll
+    for (int t = 0; t < PF; ++t) fetch_w(t, t);
+    stage_a();
+    store_w(0, 0);
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        const int t = kh * 5 + kw;
+        __syncthreads();       // sW[t & 1] and the wave's staged rows are complete, sW[(t + 1) & 1] is free
+        if (kw == 0 && kh + 1 < 5) fetch_a(kh + 1);           // the registers the rows were split from are free
+        if (t + PF < 25) fetch_w(t + PF, t % PF);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* w = sW[t & 1];
+        const int rho = rho0 + ((kw & 1) * HALF + (kw >> 1)) * R;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          bf16x8 xa[3];
+          const int ao = tile_off<KC>(rho, 2 * kk + h);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) xa[p] = as_frag(*reinterpret_cast<const u32x4*>(myA + p * PLANE_A + ao));
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            bf16x8 wb[3];
+            const int wo = wrow_off<KC>(nt * 32 + i, 2 * kk + h);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wb[p] = as_frag(*reinterpret_cast<const u32x4*>(w + p * PLANE_W + wo));
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[2], wb[0], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1], wb[1], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], wb[2], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1], wb[0], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], wb[1], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], wb[0], acc[nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (t + 1 < 25) store_w((t + 1) % PF, (t + 1) & 1);
+        if (kw == 4 && kh + 1 < 5) stage_a();                 // wave-private region: this wave's reads of it are done
+      }
+    }
+    // ---- epilogue (as k_conv_taps_s): bias, row offsets through the idle staging region, buffer stores
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias ? bias : in)[nt * 32 + i];
+    unsigned* sOff = reinterpret_cast<unsigned*>(myA);
+    __builtin_amdgcn_wave_barrier();
+    if (h == 0) sOff[i] = (ptile + i < Mc) ? (ptile + i) * (unsigned)NC * 4u : 0x80000000u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned offs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) offs[r] = sOff[(r & 3) + 8 * (r >> 2) + 4 * h];
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)out_bytes, 0x00020000);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const unsigned n4 = (unsigned)(nt * 32 + i) * 4u;
+      const float b = bias ? bv[nt] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[nt][r] + b), orsrc, offs[r] + n4, 0, 0);
+    }
+  }
+};
+
+template <int KC, int NC, int COLS, int NW>
+__global__ void __launch_bounds__(64 * NW, KC == 32 ? 2 : 1)
+k_convf_rows_s(const float* __restrict__ in, const char* __restrict__ Wp, const float* __restrict__ bias,
+               float* __restrict__ out, ConvGeom g, unsigned in_bytes, unsigned out_bytes) {
+  using K = ConvFRowsS<KC, NC, COLS, NW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char (*sW)[K::TAPB] = reinterpret_cast<char (*)[K::TAPB]>(smem);
+  char* sA = smem + 2 * K::TAPB;
+  const int wave = threadIdx.x >> 6;
+  const unsigned Mc = (unsigned)(g.B * g.OH * g.OW);
+  const unsigned p0 = blockIdx.x * (32u * NW);
+  if (p0 >= Mc) return;                         // block-uniform
+  K::run(in, Wp, bias, out, g, in_bytes, out_bytes, sW, sA + wave * 3 * K::PLANE_A, p0, Mc);
+}
+template <int KC, int NC, int COLS>
+static bool launch_convf_rows(const float* in, const char* pF, const float* bias, float* out, const ConvGeom& g, unsigned in_bytes,
+                              unsigned out_bytes, hipStream_t s) {
+  using K = ConvFRowsS<KC, NC, COLS, 4>;
+  constexpr int lds = 2 * K::TAPB + 4 * 3 * K::PLANE_A;
+  static_assert(lds <= 160 * 1024, "staged rows do not fit the LDS");
+  static const bool attr = hipFuncSetAttribute((const void*)k_convf_rows_s<KC, NC, COLS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               lds) == hipSuccess;
+  if (!attr) return false;
+  const int64_t Mc = (int64_t)g.B * g.OH * g.OW;
+  hipLaunchKernelGGL((k_convf_rows_s<KC, NC, COLS, 4>), dim3((unsigned)((Mc + 127) / 128)), dim3(256), lds, s, in, pF, bias, out, g,
+                     in_bytes, out_bytes);
+  return true;
+}
+
 int64_t split_planes_bytes(const ConvGeom& g);
 bool launch_conv_taps_mfma(bool transposed, const float* in, const float* w, const float* bias, float* out, const ConvGeom& g,
                            hipStream_t s);           // kernels_mfma.hip (the self-test's control experiment)
@@ -1033,6 +1235,20 @@ bool launch_conv_taps_split(bool transposed, const float* in, const void* planes
     if (g.CO == 32) hipLaunchKernelGGL((k_convt_merged_s<32, 64, 4>), gm, dim3(256), 0, s, in, pTm, bias, out, g, in_bytes, out_bytes);
     else hipLaunchKernelGGL((k_convt_merged_s<64, 32, 4>), gm, dim3(256), 0, s, in, pTm, bias, out, g, in_bytes, out_bytes);
     return true;
+  }
+  // F-form with the input rows of a kernel row staged in LDS: output width a power of two up to 32, or a multiple of 32
+  static const bool rows = [] { const char* e = getenv("MVAE_CONVF_ROWS"); return e ? atoi(e) != 0 : true; }();
+  if (!transposed && rows && (g.OW % 32 == 0 || g.OW == 16 || g.OW == 8 || g.OW == 4)) {
+    const char* pFr = static_cast<const char*>(planes);
+    const int cols = g.OW >= 32 ? 32 : g.OW;
+    bool ok = false;
+#define MVAE_CR(A, B_) (cols == 32 ? launch_convf_rows<A, B_, 32>(in, pFr, bias, out, g, in_bytes, out_bytes, s)          \
+                        : cols == 16 ? launch_convf_rows<A, B_, 16>(in, pFr, bias, out, g, in_bytes, out_bytes, s)        \
+                        : cols == 8 ? launch_convf_rows<A, B_, 8>(in, pFr, bias, out, g, in_bytes, out_bytes, s)          \
+                                    : launch_convf_rows<A, B_, 4>(in, pFr, bias, out, g, in_bytes, out_bytes, s))
+    if (g.CI == 32) ok = MVAE_CR(32, 64); else ok = MVAE_CR(64, 32);
+#undef MVAE_CR
+    if (ok) return true;
   }
   // PF taps of register prefetch: 3 where a tap's pixels are 16 registers (KC = 32), 2 where they are 32 (KC = 64)
 #define MVAE_CS(A, B_, TF, PF_, P) hipLaunchKernelGGL((k_conv_taps_s<A, B_, TF, PF_, 4>), grid, dim3(256), 0, s, in, P, bias, out, g, in_bytes, out_bytes)
