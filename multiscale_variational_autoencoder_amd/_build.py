@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmvae_hip.so")
-SOURCES = ["kernels_generic.hip", "kernels_mfma.hip", "kernels_opt.hip", "kernels_edge.hip", "kernels_dw.hip", "kernels_dense.hip", "kernels_se.hip", "kernels_bf16.hip", "kernels_split.hip", "kernels_fused.hip", "kernels_fused_fwd.hip", "kernels_blocks.hip", "kernels_layers.hip", "dispatch.hip", "layer_ops.cpp", "runtime.cpp"]
+SOURCES = ["kernels_generic.hip", "kernels_mfma.hip", "kernels_opt.hip", "kernels_edge.hip", "kernels_dw.hip", "kernels_dense.hip", "kernels_se.hip", "kernels_bf16.hip", "kernels_split.hip", "kernels_split_wgrad.hip", "kernels_fused.hip", "kernels_fused_fwd.hip", "kernels_blocks.hip", "kernels_layers.hip", "dispatch.hip", "layer_ops.cpp", "runtime.cpp"]
 HEADERS = ["kernels.h", "act16.h", "prof.h", "split.h", os.path.join("..", "..", "include", "mvae_hip.h")]
 
 

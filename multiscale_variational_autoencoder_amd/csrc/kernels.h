@@ -349,6 +349,8 @@ bool mn_fwd_first_split_on();
 void fused_launch_note(bool fwd, int B, int grid);
 void fused_launch_stats(int out[3]);
 int split_conv_status();               // 0 switched off (MVAE_SPLIT_CONV=0), 1 in use, 2 disabled by the self-test on this board
+// 5 x 5 weight gradient (32 <-> 64 channels) with split-bf16 products (kernels_split_wgrad.hip); false = not covered / off
+bool launch_conv_wgrad_split(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, hipStream_t s);
 bool launch_conv_taps_split(bool transposed, const float* in, const void* planes, const float* bias, float* out,
                             const ConvGeom& g, hipStream_t s);
 

@@ -747,12 +747,20 @@ static void run_wgrad_rows(const float* big, const float* small, float* dW, floa
                      sl.at(db), g, pre, M, rpb, sl.count(), sl.stride);
 }
 
+// the float32-MFMA 5 x 5 kernel by itself (tools/conv_probe_s.cpp times it next to the split-bf16 one)
+bool launch_conv_wgrad_taprow_f32(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, hipStream_t s) {
+  if (g.CI == 64 && g.CO == 32) return run_wgrad_taprow<64, 32>(big, small, dW, db, g, s);
+  if (g.CI == 32 && g.CO == 64) return run_wgrad_taprow<32, 64>(big, small, dW, db, g, s);
+  return false;
+}
+
 bool launch_conv_wgrad_mfma(const float* big, const float* small, float* dW, float* db, const ConvGeom& g, PreOp pre, GradSlots sl,
                             hipStream_t s) {
   if (g.CI < 4 || 2 * g.OW < 64 / (g.CI / 4)) return false;   // the kernel's branch-free row stepping wraps at most twice
 #define MVAE_WG(A, B_)                                                          \
   if (g.CI == A && g.CO == B_) {                                                \
-    if (!(g.KW == 5 && !pre.scale && !pre.gate && !det_mode() && run_wgrad_taprow<A, B_>(big, small, dW, db, g, s)))  \
+    if (!(g.KW == 5 && !pre.scale && !pre.gate && !det_mode() &&                                                      \
+          (launch_conv_wgrad_split(big, small, dW, db, g, s) || run_wgrad_taprow<A, B_>(big, small, dW, db, g, s))))    \
       run_wgrad_rows<A, B_>(big, small, dW, db, g, pre, sl, s);                     \
     return true;                                                                \
   }

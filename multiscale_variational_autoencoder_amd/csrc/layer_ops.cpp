@@ -22,6 +22,12 @@ ConvGeom conv_geom(int B, int H, int W, int C, int F, int kh, int kw, int sh, in
   return ConvGeom{B, H, W, C, oh, ow, F, kh, kw, sh, sw, pt, pl};
 }
 int done() { return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP; }
+// stateless entry points never inherit a handle's deterministic-reduction mode (a process-global launcher switch)
+bool use_device(int device) {
+  if (hipSetDevice(device) != hipSuccess) return false;
+  set_det_mode(false);
+  return true;
+}
 }  // namespace
 
 extern "C" {
@@ -29,7 +35,7 @@ extern "C" {
 int mvae_conv2d_forward(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, const float* b,
                         int32_t F, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t relu, float* y, void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || F <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   PreOp none{nullptr, nullptr, nullptr};
   launch_conv_f(x, w, b, nullptr, y, conv_geom(B, H, W, C, F, kh, kw, sh, sw), none, relu ? ACT_RELU : ACT_NONE,
                 static_cast<hipStream_t>(stream));
@@ -41,7 +47,7 @@ int mvae_conv2d_backward(int32_t device, const float* x, const float* dpre, int3
                          void* stream) {
   if (!x || !dpre || !w || !dw || B <= 0 || H <= 0 || W <= 0 || C <= 0 || F <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0)
     return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const ConvGeom g = conv_geom(B, H, W, C, F, kh, kw, sh, sw);
   PreOp none{nullptr, nullptr, nullptr};
@@ -54,7 +60,7 @@ int mvae_conv2d_backward(int32_t device, const float* x, const float* dpre, int3
 int mvae_depthwise3x3_forward(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w,
                               const float* b, float* y, void* stream) {
   if (!x || !w || !b || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   launch_dw_fwd(x, w, b, y, B, H, W, C, static_cast<hipStream_t>(stream));          // 3x3, SAME, bias, ReLU
   return done();
 }
@@ -62,7 +68,7 @@ int mvae_depthwise3x3_forward(int32_t device, const float* x, int32_t B, int32_t
 int mvae_depthwise3x3_backward(int32_t device, const float* x, const float* y, const float* dy, int32_t B, int32_t H, int32_t W,
                                int32_t C, const float* w, float* dx, float* dw, float* db, float* work, void* stream) {
   if (!x || !y || !dy || !w || !dx || !dw || !db || !work || B <= 0 || H <= 0 || W <= 0 || C <= 0) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   hipStream_t s = static_cast<hipStream_t>(stream);
   launch_relu_bwd(dy, y, work, (int64_t)B * H * W * C, s);                            // through the ReLU
   launch_dw_wgrad(x, work, dw, db, B, H, W, C, s);
@@ -72,7 +78,7 @@ int mvae_depthwise3x3_backward(int32_t device, const float* x, const float* y, c
 
 int mvae_activation_forward(int32_t device, int32_t act, const float* x, float* y, int64_t n, float param, void* stream) {
   if (!x || !y || n <= 0 || act < 0 || act > LAYER_ACT_ATTENUATE) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   launch_act_fwd(act, x, y, n, param, static_cast<hipStream_t>(stream));
   return done();
 }
@@ -80,14 +86,14 @@ int mvae_activation_forward(int32_t device, int32_t act, const float* x, float* 
 int mvae_activation_backward(int32_t device, int32_t act, const float* y, const float* dy, float* dx, int64_t n, float param,
                              void* stream) {
   if (!y || !dy || !dx || n <= 0 || act < 0 || act > LAYER_ACT_ATTENUATE) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   launch_act_bwd(act, y, dy, dx, n, param, static_cast<hipStream_t>(stream));
   return done();
 }
 
 int mvae_eltwise(int32_t device, int32_t op, const float* a, const float* b, float* out, int64_t n, void* stream) {
   if (!a || !b || !out || n <= 0 || op < 0 || op > 2) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   launch_eltwise(op, a, b, out, n, static_cast<hipStream_t>(stream));
   return done();
 }
@@ -95,7 +101,7 @@ int mvae_eltwise(int32_t device, int32_t op, const float* a, const float* b, flo
 int mvae_scale_channels_forward(int32_t device, const float* x, const float* m, float* y, int32_t B, int64_t HW, int32_t C,
                                 void* stream) {
   if (!x || !m || !y || B <= 0 || HW <= 0 || C <= 0) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   launch_scale_channels(x, m, y, B, HW, C, static_cast<hipStream_t>(stream));
   return done();
 }
@@ -103,7 +109,7 @@ int mvae_scale_channels_forward(int32_t device, const float* x, const float* m, 
 int mvae_scale_channels_backward(int32_t device, const float* x, const float* m, const float* dy, float* dx, float* dm, int32_t B,
                                  int64_t HW, int32_t C, void* stream) {
   if (!x || !m || !dy || B <= 0 || HW <= 0 || C <= 0 || (!dx && !dm)) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dx) launch_scale_channels(dy, m, dx, B, HW, C, s);
   if (dm) launch_scale_channels_bwd_m(x, dy, dm, B, HW, C, s);
@@ -112,7 +118,7 @@ int mvae_scale_channels_backward(int32_t device, const float* x, const float* m,
 
 int mvae_global_maxpool_forward(int32_t device, const float* x, float* y, int32_t* idx, int32_t B, int64_t HW, int32_t C, void* stream) {
   if (!x || !y || !idx || B <= 0 || HW <= 0 || HW >= (1LL << 31) || C <= 0) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   launch_gmax_fwd(x, y, idx, B, HW, C, static_cast<hipStream_t>(stream));
   return done();
 }
@@ -120,7 +126,7 @@ int mvae_global_maxpool_forward(int32_t device, const float* x, float* y, int32_
 int mvae_global_maxpool_backward(int32_t device, const float* dy, const int32_t* idx, float* dx, int32_t B, int64_t HW, int32_t C,
                                  void* stream) {
   if (!dy || !idx || !dx || B <= 0 || HW <= 0 || C <= 0) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   launch_gmax_bwd(dy, idx, dx, B, HW, C, static_cast<hipStream_t>(stream));
   return done();
 }
@@ -128,7 +134,7 @@ int mvae_global_maxpool_backward(int32_t device, const float* dy, const int32_t*
 int mvae_maxpool_same_forward(int32_t device, const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ph, int32_t pw,
                               int32_t sh, int32_t sw, float* y, int32_t* idx, void* stream) {
   if (!x || !y || !idx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ph <= 0 || pw <= 0 || sh <= 0 || sw <= 0) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   int oh, ow, pt, pl;
   same_pad1(H, ph, sh, &oh, &pt);
   same_pad1(W, pw, sw, &ow, &pl);
@@ -139,7 +145,7 @@ int mvae_maxpool_same_forward(int32_t device, const float* x, int32_t B, int32_t
 int mvae_maxpool_same_backward(int32_t device, const float* dy, const int32_t* idx, int32_t B, int32_t H, int32_t W, int32_t C,
                                int32_t ph, int32_t pw, int32_t sh, int32_t sw, float* dx, void* stream) {
   if (!dy || !idx || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ph <= 0 || pw <= 0 || sh <= 0 || sw <= 0) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   int oh, ow, pt, pl;
   same_pad1(H, ph, sh, &oh, &pt);
   same_pad1(W, pw, sw, &ow, &pl);
@@ -152,7 +158,7 @@ int mvae_batchnorm_forward(int32_t device, const float* x, int64_t M, int32_t C,
                            float* batch_var, float* y, void* stream) {
   if (!x || !gamma || !beta || !mean || !invstd || !y || M <= 0 || C <= 0) return MVAE_E_INVALID;
   if (!training && (!moving_mean || !moving_var)) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (training) launch_bn_rows_stats(x, mean, invstd, batch_var, M, C, eps, s);
   else launch_bn_rows_from_moving(moving_mean, moving_var, mean, invstd, C, eps, s);
@@ -164,7 +170,7 @@ int mvae_batchnorm_backward(int32_t device, const float* x, const float* dy, int
                             const float* mean, const float* invstd, int32_t training, float* dx, float* dgamma, float* dbeta,
                             float* work, void* stream) {
   if (!x || !dy || !gamma || !mean || !invstd || !dx || !dgamma || !dbeta || !work || M <= 0 || C <= 0) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float *s1 = work, *s2 = work + C;                       // this call's column sums (dgamma / dbeta may hold earlier terms)
   launch_zero(work, 2 * (int64_t)C, s);
@@ -178,7 +184,7 @@ int mvae_batchnorm_backward(int32_t device, const float* x, const float* dy, int
 int mvae_attention_core_forward(int32_t device, const float* theta, const float* phi, const float* g, int32_t B, int64_t HW, int32_t F,
                                 float* scores, float* out, void* stream) {
   if (!theta || !phi || !g || !scores || !out || B <= 0 || HW <= 0 || F <= 0 || F > 64) return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   if (!launch_attention_core_fwd(theta, phi, g, scores, out, B, HW, F, static_cast<hipStream_t>(stream))) return MVAE_E_INVALID;
   return done();
 }
@@ -188,7 +194,7 @@ int mvae_attention_core_backward(int32_t device, const float* theta, const float
                                  float* work, void* stream) {
   if (!theta || !phi || !g || !scores || !dout || !dtheta || !dphi || !dg || !work || B <= 0 || HW <= 0 || F <= 0 || F > 64)
     return MVAE_E_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  if (!use_device(device)) return MVAE_E_HIP;
   if (!launch_attention_core_bwd(theta, phi, g, scores, dout, dtheta, dphi, dg, work, B, HW, F, static_cast<hipStream_t>(stream)))
     return MVAE_E_INVALID;
   return done();

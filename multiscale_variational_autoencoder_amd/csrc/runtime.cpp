@@ -1591,6 +1591,7 @@ int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_sca
   if (!h) return MVAE_E_INVALID;
   if (!h->bound) return fail(h, MVAE_E_STATE, "mvae_bind has not been called");
   hipStream_t s0 = static_cast<hipStream_t>(stream);
+  set_det_mode(h->det);                     // (process-global launcher switch: every entry point sets it from ITS handle)
   const int Bt = h->last_train_B;
   const bool clip = clip_norm > 0.f;
   launch_set_f3(h->d_hp + HP_LR, lr, clip_norm, grad_scale, 3, s0);     // HP_LR, HP_CLIP, HP_GRAD_SCALE are adjacent
@@ -1770,6 +1771,7 @@ int mvae_gather_rows(int32_t device, const float* src, const int64_t* idx, int64
                      void* stream) {
   if (!src || !idx || !dst || n < 0 || row_elems <= 0) return MVAE_E_INVALID;
   if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  set_det_mode(false);                      // stateless entry point: never inherits a handle's deterministic mode
   launch_gather_rows(src, idx, dst, n, row_elems, static_cast<hipStream_t>(stream));
   return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_E_HIP;
 }
@@ -1781,6 +1783,7 @@ int mvae_laplacian_split(int32_t device, const float* x, int32_t batch, int32_t 
   if (!x || !gauss9 || !out || !work || batch <= 0 || C <= 0 || C > 8 || levels < 1 || levels > MVAE_MAX_LEVELS) return MVAE_E_INVALID;
   if (H <= 0 || W <= 0 || (H % (1 << (levels - 1))) || (W % (1 << (levels - 1)))) return MVAE_E_INVALID;
   if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  set_det_mode(false);                      // stateless entry point: never inherits a handle's deterministic mode
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n0 = (int64_t)batch * H * W * C;
   // level 0 reads the raw image and normalises on the fly; work holds the normalised image of levels 1 .. levels-2
@@ -1809,6 +1812,7 @@ int mvae_laplacian_merge(int32_t device, const float* const* in, int32_t batch, 
   if (!in || !out || !work || batch <= 0 || C <= 0 || C > 8 || levels < 1 || levels > MVAE_MAX_LEVELS) return MVAE_E_INVALID;
   if (H <= 0 || W <= 0 || (H % (1 << (levels - 1))) || (W % (1 << (levels - 1)))) return MVAE_E_INVALID;
   if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  set_det_mode(false);                      // stateless entry point: never inherits a handle's deterministic mode
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (levels == 1) {
     launch_denorm_clip(in[0], out, (int64_t)batch * H * W * C, min_value, max_value, s);
@@ -1835,6 +1839,7 @@ int mvae_laplacian_merge_mix(int32_t device, const float* const* in, int32_t bat
     return MVAE_E_INVALID;
   if (H <= 0 || W <= 0 || (H % (1 << (levels - 1))) || (W % (1 << (levels - 1)))) return MVAE_E_INVALID;
   if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  set_det_mode(false);                      // stateless entry point: never inherits a handle's deterministic mode
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n0 = (int64_t)batch * H * W;
   if (levels == 1) {
@@ -1875,6 +1880,7 @@ int mvae_mnv2_forward(int32_t device, const float* x, int32_t B, int32_t H, int3
   if (!x || !w0 || !b0 || !wd || !bd || !w2 || !b2 || !t0 || !t1 || !u || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || F <= 0)
     return MVAE_E_INVALID;
   if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  set_det_mode(false);                      // stateless entry point: never inherits a handle's deterministic mode
   hipStream_t s = static_cast<hipStream_t>(stream);
   PreOp none{nullptr, nullptr, nullptr};
   launch_conv_f(x, w0, b0, nullptr, t0, geom_same(B, H, W, C, F, 1, 1), none, ACT_NONE, s);      // conv0: 1x1, linear (:503-511)
@@ -1892,6 +1898,7 @@ int mvae_mnv2_backward(int32_t device, const float* x, const float* t0, const fl
       B <= 0 || H <= 0 || W <= 0 || C <= 0 || F <= 0)
     return MVAE_E_INVALID;
   if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  set_det_mode(false);                      // stateless entry point: never inherits a handle's deterministic mode
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t M = (int64_t)B * H * W;
   float *du = work, *d1 = work + M * C, *dt0 = d1 + M * F;
@@ -1916,6 +1923,7 @@ int mvae_resnet_forward(int32_t device, const float* x, int32_t B, int32_t H, in
     return MVAE_E_INVALID;
   if (C != F && (!ws || !bs || !skip)) return MVAE_E_INVALID;              // a 1x1 skip convolution when the widths differ
   if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  set_det_mode(false);                      // stateless entry point: never inherits a handle's deterministic mode
   hipStream_t s = static_cast<hipStream_t>(stream);
   PreOp none{nullptr, nullptr, nullptr};
   launch_conv_f(x, w0, b0, nullptr, x0, geom_same(B, H, W, C, F, kh, kw), none, relu ? ACT_RELU : ACT_NONE, s);   // conv0 (:830-838)
@@ -1935,6 +1943,7 @@ int mvae_resnet_backward(int32_t device, const float* x, const float* x0, const 
     return MVAE_E_INVALID;
   if (C != F && (!ws || !dws || !dbs)) return MVAE_E_INVALID;
   if (hipSetDevice(device) != hipSuccess) return MVAE_E_HIP;
+  set_det_mode(false);                      // stateless entry point: never inherits a handle's deterministic mode
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t M = (int64_t)B * H * W;
   float *dpre = work, *d0 = work + M * F, *tmp = d0 + M * F;               // [M,F], [M,F], [M,C]
