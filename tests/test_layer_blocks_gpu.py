@@ -2,7 +2,7 @@
 resnet_block with strides / BatchNormalization, mobilenetV2_block with BatchNormalization; reference
 mvae/layer_blocks.py:191-412, 468-550, 654-887) assembled from the HIP layer operators, against the float64 oracle
 (oracle/blocks_oracle.py).  Tolerances (float32 kernels vs float64): outputs <= 2e-6 relative (norm-wise), input gradient
-<= 2e-5, weight gradients <= 2e-5 per tensor (the bars of tests/test_blocks_v2_resnet.py); blocks with BatchNormalization
+<= 2e-5, weight gradients <= 2e-5 per tensor (the bars of tests/test_blocks_v2_resnet.py; bias / BatchNorm vectors 4x that); blocks with BatchNormalization
 over a small batch or max pooling get 1e-4 (normalisation amplifies rounding; documented per case)."""
 import numpy as np
 import pytest
@@ -41,7 +41,8 @@ def _check(kind, blk, x, out_shape, tol=(2e-6, 2e-5, 2e-5), training=True, **kw)
     gscale = max(np.linalg.norm(g) for g in Gr.values())
     for k, g in Gr.items():
         err = np.linalg.norm((G[k].astype(np.float64) - g).ravel()) / max(np.linalg.norm(g.ravel()), 1e-3 * gscale)
-        assert err <= tol[2], (k, err)
+        # bias / BatchNorm vectors are plain column sums over all pixels of terms of both signs: 4x the weights' bar
+        assert err <= tol[2] * (4 if g.ndim == 1 else 1), (k, err)
     return y
 
 
