@@ -5,7 +5,7 @@ import collections, csv, glob, sys
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for d in sys.argv[1:]:
-    for f in glob.glob(d + '/*/*_counter_collection.csv'):
+    for f in glob.glob(d + '/*/*_counter_collection.csv') + glob.glob(d + '/*_counter_collection.csv'):
         seen = set()
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name'].split('(')[0].replace('void ', '')
