@@ -968,6 +968,16 @@ bool debug_skip_scale(int si) {
 #else
 constexpr bool debug_skip_scale(int) { return false; }
 #endif
+// Order in which the scales' chains are issued (and therefore captured into the graph).  A replayed hipGraph is enqueued by
+// the host node by node in creation order at ~2 us per kernel node (3.7 us under rocprofv3): with the small scales first,
+// scale 0 -- the long pole, 112 kernels of 3.7 ms -- had its first kernel enqueued 0.45 ms (forward) / 0.6 ms (backward) after
+// the fork, behind the ~230 nodes of the other scales (rocprofv3 kernel trace, tools/trace_streams.py: queue of scale 0 idle
+// for exactly that long at both forks).  Scale 0 first: its chain starts at the fork and the short chains fill in beside it.
+// MVAE_SCALE_ORDER=0 restores small-scales-first.
+static bool scale0_first() {
+  static const bool v = [] { const char* e = getenv("MVAE_SCALE_ORDER"); return e ? atoi(e) != 0 : true; }();
+  return v;
+}
 void fork_scales(mvae_handle* h, hipStream_t main) {
   if (serial_scales(h)) return;
   (void)hipEventRecord(h->ev_fork, main);
@@ -1281,7 +1291,8 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
     // ---- per-scale VAE: the scales are independent until the merge -> one stream each
     fork_scales(h, s);
     PreOp none{nullptr, nullptr, nullptr};
-    for (int si = L - 1; si >= 0; --si) {
+    for (int ord = 0; ord < L; ++ord) {
+      const int si = scale0_first() ? ord : L - 1 - ord;
       if (debug_skip_scale(si)) continue;
       hipStream_t ss = scale_stream(h, si, s);
       profiler().cur_scale = si;
@@ -1553,7 +1564,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
   // (Holding the smaller scales back until scale 0 reaches its MFMA-bound 5x5 convolutions, so that their HBM-bound work
   // would fill those windows, was measured: 5.88 .. 6.05 ms against 5.92 -- their chains are latency-bound and only move
   // the contention.  They start at the fork.)
-  for (int si = L - 1; si >= 0; --si) scale_half(si, phase);
+  for (int ord = 0; ord < L; ++ord) scale_half(scale0_first() ? ord : L - 1 - ord, phase);
   join_scales(h, s_main);
   profiler().cur_scale = -1;
   if ((phase & 2) && h->gslots.n)
