@@ -122,6 +122,10 @@ int mvae_packed_f32_hazard(int32_t* beside_split, int32_t* beside_bf16);
 /* Launch geometry of the image-resident fused MobileNetV3 kernels (k_mn_fwd_chain_s / k_dw_bwd_conv0_s: one block per CU
  * walks whole images) since the process started: launches of the forward / backward kernel and the largest number of
  * images one block walked.  Diagnostic: the parity tests assert that their multi-image cases really exercised that path. */
+/* MVAE_STAMPS=1 in the environment of mvae_create: the step's graphs carry one-thread kernels that store the 100 MHz device
+ * clock at the forks, joins and chain ends (ids in csrc/runtime.cpp, stamp()).  Copies the first n (<= 128) stamps to the
+ * host after a device synchronise; MVAE_E_STATE when the handle was created without the switch.  Diagnostic. */
+int mvae_stamps(const mvae_handle* h, uint64_t* out, int32_t n);
 int mvae_fused_launch_stats(int32_t* fwd, int32_t* bwd, int32_t* max_images_per_block);
 
 /* ---- tables: the layer/variable inventory Keras builds ---- */

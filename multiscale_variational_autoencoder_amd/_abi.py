@@ -52,6 +52,7 @@ SYMBOLS = {
     "mvae_split_conv_status": (C.c_int, []),
     "mvae_split_conv_erratum": (C.c_int, []),
     "mvae_packed_f32_hazard": (C.c_int, [C.POINTER(C.c_int32)] * 2),
+    "mvae_stamps": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_int32]),
     "mvae_fused_launch_stats": (C.c_int, [C.POINTER(C.c_int32)] * 3),
     "mvae_create": (C.c_int, [C.POINTER(MvaeConfig), C.POINTER(_H)]),
     "mvae_destroy": (None, [_H]),

@@ -115,6 +115,9 @@ void launch_zero(float* p, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_zero, dim3(grid_for(n)), dim3(kBlock), 0, s, p, n);
 }
 __global__ void k_set_u64(uint64_t* dst, uint64_t v) { *dst = v; }
+// the constant-frequency (100 MHz) device clock -> *dst (diagnostic time stamps inside replayed graphs: runtime.cpp stamp())
+__global__ void k_stamp(uint64_t* dst) { *dst = wall_clock64(); }
+void launch_stamp(uint64_t* dst, hipStream_t s) { hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, s, dst); }
 void launch_set_u64(uint64_t* dst, uint64_t v, hipStream_t s) { hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, s, dst, v); }
 __global__ void k_set_f3(float* dst, float a, float b, float c, int n) {
   if (n > 0) dst[0] = a;

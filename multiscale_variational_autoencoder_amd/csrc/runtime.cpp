@@ -136,7 +136,9 @@ struct mvae_handle {
         *losses = nullptr, *sgn = nullptr, *reg_tmp = nullptr;
   uint64_t* d_seed = nullptr;
   float* d_hp = nullptr;                    // kernels.h HP_*: loss factors, lr, clip, grad_scale (device-resident)
-  int64_t off_seed = 0, off_hp = 0;
+  int64_t off_seed = 0, off_hp = 0, off_stamps = 0;
+  uint64_t* d_stamps = nullptr;             // MVAE_STAMPS=1: device time stamps at the forks / joins of a step (diagnostic)
+  bool stamps = false;
   // concurrency: scale 0 runs on the caller's stream, every other scale on its own side stream (fork/join with
   // events); each ABI call is captured into a hipGraph per argument signature and replayed.
   // wgrad_streams (MVAE_WGRAD_STREAMS): 0 (default) = weight gradients stay on their scale's chain.  2 = the k x k
@@ -502,6 +504,7 @@ int build_plan(mvae_handle* h) {
   h->off_norms = b.ws_alloc(2 * (int64_t)h->chunks.size());      // one partial ||g||^2 per chunk, then one total per tensor
   h->off_seed = b.ws_alloc(kAlign);
   h->off_hp = b.ws_alloc(kAlign);
+  h->off_stamps = b.ws_alloc(4 * kAlign);                    // 128 uint64 time stamps (MVAE_STAMPS=1, mvae_stamps)
   h->off_slots = b.ws_alloc((int64_t)h->nslots * h->P);
   h->ws_floats = b.wcur;
   return MVAE_OK;
@@ -534,6 +537,7 @@ void rebase_all(mvae_handle* h) {
   rb(h->xin);
   h->d_seed = reinterpret_cast<uint64_t*>(base + h->off_seed);
   h->d_hp = base + h->off_hp;
+  h->d_stamps = reinterpret_cast<uint64_t*>(base + h->off_stamps);
   rb(h->eps_buf); rb(h->noise_buf); rb(h->keep_buf); rb(h->recon); rb(h->losses); rb(h->sgn); rb(h->reg_tmp);
   h->d_chunks = reinterpret_cast<ChunkDesc*>(base + h->off_chunks);
   h->d_sdescs = reinterpret_cast<StateDesc*>(base + h->off_sdescs);
@@ -968,15 +972,23 @@ bool debug_skip_scale(int si) {
 #else
 constexpr bool debug_skip_scale(int) { return false; }
 #endif
-// Order in which the scales' chains are issued (and therefore captured into the graph).  A replayed hipGraph is enqueued by
-// the host node by node in creation order at ~2 us per kernel node (3.7 us under rocprofv3): with the small scales first,
-// scale 0 -- the long pole, 112 kernels of 3.7 ms -- had its first kernel enqueued 0.45 ms (forward) / 0.6 ms (backward) after
-// the fork, behind the ~230 nodes of the other scales (rocprofv3 kernel trace, tools/trace_streams.py: queue of scale 0 idle
-// for exactly that long at both forks).  Scale 0 first: its chain starts at the fork and the short chains fill in beside it.
-// MVAE_SCALE_ORDER=0 restores small-scales-first.
+// Order in which the scales' chains are issued (and captured).  Default: the small scales first, scale 0 -- the long pole -- last
+// on the caller's stream.  MVAE_SCALE_ORDER=1 issues scale 0 first: measured 4.90 against 4.84 ms (C32-nb) and 21.95 against
+// 20.95 ms (C256-nb bf16) -- the big kernels then own the chip from the start and the latency-bound small chains run out
+// alone at the end.  (A rocprofv3 kernel trace suggests the opposite -- scale 0's queue idle for 0.4 - 0.6 ms behind each fork --
+// because the tracer serialises the dispatches of a graph replay on the host; the in-graph time stamps of MVAE_STAMPS=1 show
+// the unperturbed timeline, tools/stamps.py.)
 static bool scale0_first() {
-  static const bool v = [] { const char* e = getenv("MVAE_SCALE_ORDER"); return e ? atoi(e) != 0 : true; }();
+  static const bool v = [] { const char* e = getenv("MVAE_SCALE_ORDER"); return e ? atoi(e) != 0 : false; }();
   return v;
+}
+// MVAE_STAMPS=1 (read at mvae_create): one-thread kernels that store the constant 100 MHz device clock at the forks, joins and
+// chain ends of a step, INSIDE the replayed graphs -- an unperturbed timeline (rocprofv3's kernel trace serialises the
+// dispatches of a graph replay on the host: under it the three scales' chains start 0.4 ms apart, without it they do not).
+// ids: 0 forward start, 1 fork, 10+i / 20+i scale i forward begin / end, 2 joined, 3 forward end; 4 backward start, 5 fork,
+// 30+i / 40+i scale i backward begin / end, 6 joined, 7 backward end; 8 / 9 apply start / end.
+void stamp(mvae_handle* h, int id, hipStream_t s) {
+  if (h->stamps && h->d_stamps && id >= 0 && id < 128) launch_stamp(h->d_stamps + id, s);
 }
 void fork_scales(mvae_handle* h, hipStream_t main) {
   if (serial_scales(h)) return;
@@ -1056,6 +1068,12 @@ int mvae_packed_f32_hazard(int32_t* beside_split, int32_t* beside_bf16) {
   if (beside_bf16) *beside_bf16 = k16_erratum_count();
   return MVAE_OK;
 }
+int mvae_stamps(const mvae_handle* h, uint64_t* out, int32_t n) {
+  if (!h || !out || n <= 0 || n > 128) return MVAE_E_INVALID;
+  if (!h->bound || !h->stamps) return MVAE_E_STATE;
+  if (hipDeviceSynchronize() != hipSuccess) return MVAE_E_HIP;
+  return hipMemcpy(out, h->d_stamps, sizeof(uint64_t) * n, hipMemcpyDeviceToHost) == hipSuccess ? MVAE_OK : MVAE_E_HIP;
+}
 int mvae_fused_launch_stats(int32_t* fwd, int32_t* bwd, int32_t* max_images_per_block) {
   int v[3];
   fused_launch_stats(v);
@@ -1106,6 +1124,7 @@ int mvae_create(const mvae_config* cfg, mvae_handle** out) {
   mvae_handle* h = new mvae_handle();
   h->cfg = *cfg;
   if (const char* v = getenv("MVAE_DETERMINISTIC")) h->det = atoi(v) != 0;
+  if (const char* v = getenv("MVAE_STAMPS")) h->stamps = atoi(v) != 0;
   if (h->det) {
     if (cfg->act_dtype != MVAE_ACT_F32) { delete h; return fail(nullptr, MVAE_E_INVALID, "MVAE_DETERMINISTIC=1 supports float32 activations only"); }
     h->nslots = kDetSlots; h->stat_slots = kDetSlots;
@@ -1271,6 +1290,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
   const float* eps = io->eps ? io->eps : h->eps_buf;
 
   auto body = [=](hipStream_t s) {
+    stamp(h, 0, s);
     const mvae_step_io* io = &io_c;
     launch_zero(metrics, (int64_t)(h->MET), s);
     // ---- randomness: injected (parity) or Philox on the device (timed runs)
@@ -1289,6 +1309,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
       launch_blur_split(sc.pcur, sc.band, h->scales[l + 1].pcur, B, sc.H, sc.W, C, s);
     }
     // ---- per-scale VAE: the scales are independent until the merge -> one stream each
+    stamp(h, 1, s);
     fork_scales(h, s);
     PreOp none{nullptr, nullptr, nullptr};
     for (int ord = 0; ord < L; ++ord) {
@@ -1297,6 +1318,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
       hipStream_t ss = scale_stream(h, si, s);
       profiler().cur_scale = si;
       Scale& sc = h->scales[si];
+      stamp(h, 10 + si, ss);
       ConvGeom g{};
       g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
       g.KH = g.KW = 3; g.SH = g.SW = 1; g.PT = g.PL = 1;
@@ -1345,13 +1367,16 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
       if (io->log_var) launch_copy_cols(sc.lv, sc.z, 0, io->log_var, (int)h->Z, sc.z_off, B, sc.z, ss);
       if (io->z) launch_copy_cols(sc.zs, sc.z, 0, io->z, (int)h->Z, sc.z_off, B, sc.z, ss);
       decoder_forward(h, sc, B, training, ss);
+      stamp(h, 20 + si, ss);
     }
     join_scales(h, s);
+    stamp(h, 2, s);
     merge_forward(h, B, h->recon, s);
     // (partial sums of large images go through scale 0's first gradient scratch buffer: free until the backward pass)
     launch_loss_fwd(xsrc, h->recon, h->losses, 3 + L, L, h->sgn, B, c.input_h, c.input_w, C, s, h->scales[0].scratch[0],
                     h->scales[0].scratch_elems * (h->scales[0].bf ? 1 : 2) / 2 * (int64_t)h->cfg.max_batch);
     launch_metrics(h->losses, 3 + L, B, metrics, s);
+    stamp(h, 3, s);
     if (io->recon) (void)hipMemcpyAsync(io->recon, h->recon, sizeof(float) * hwC * B, hipMemcpyDeviceToDevice, s);
     if (io->losses)
       (void)hipMemcpyAsync(io->losses, h->losses, sizeof(float) * (3 + L) * B, hipMemcpyDeviceToDevice, s);
@@ -1384,6 +1409,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
   // phase bit 2: encoder halves, conv_base, gradient-slot fold.  3 = the whole pass in one graph.
   auto body = [=](hipStream_t s) {
   PreOp none{nullptr, nullptr, nullptr};
+  if (phase & 1) stamp(h, 4, s);
   if (phase & 1) {
   h->ev_next = 0;
   launch_zero(G, (int64_t)(h->P), s);
@@ -1394,6 +1420,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
   for (int i = 0; i + 1 < L; ++i)
     launch_upsample_bwd(h->scales[i].dy, h->scales[i + 1].dy, B, h->scales[i + 1].H, h->scales[i + 1].W, C, s);
   }
+  stamp(h, 5, s);
   fork_scales(h, s);
   hipStream_t s_main = s;
   // One scale's backward: `bits` & 1 = decoder half (ends with sc.d_mid), & 2 = encoder half.
@@ -1404,6 +1431,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
     Scale& sc = h->scales[si];
     const int64_t M = (int64_t)B * sc.H * sc.W;
     float* d = nullptr;
+    if (bits & 1) stamp(h, 30 + si, s);
     if (bits & 1) {
     for (int k = 0; k < 4; ++k) { sc.scratch_used[k] = false; sc.buf_pending[k] = false; }
     launch_zero(sc.dg, (int64_t)sc.dg_total * B * sc.cmax, s);   // squeeze-excite gate gradients (all slot copies)
@@ -1560,15 +1588,18 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
       launch_conv_wgrad(sc.band, d, G + sc.cb_w, G + sc.cb_b, g, none, h->gslots, s);
     }
     release(sc, d);
+    stamp(h, 40 + si, s);
   };
   // (Holding the smaller scales back until scale 0 reaches its MFMA-bound 5x5 convolutions, so that their HBM-bound work
   // would fill those windows, was measured: 5.88 .. 6.05 ms against 5.92 -- their chains are latency-bound and only move
   // the contention.  They start at the fork.)
   for (int ord = 0; ord < L; ++ord) scale_half(scale0_first() ? ord : L - 1 - ord, phase);
   join_scales(h, s_main);
+  stamp(h, 6, s_main);
   profiler().cur_scale = -1;
   if ((phase & 2) && h->gslots.n)
     launch_slot_sum(h->d_slot_chunks, (int)h->slot_chunks.size(), G, h->gslots.base, h->gslots.stride, h->gslots.n, s_main);
+  stamp(h, 7, s_main);
   };
   int rc = MVAE_OK;
   if (h->last_x == h->xin && h->last_eps == h->eps_buf)
@@ -1607,10 +1638,12 @@ int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_sca
   const bool clip = clip_norm > 0.f;
   launch_set_f3(h->d_hp + HP_LR, lr, clip_norm, grad_scale, 3, s0);     // HP_LR, HP_CLIP, HP_GRAD_SCALE are adjacent
   auto body = [=](hipStream_t s) {
+    stamp(h, 8, s);
     launch_opt_prepare(h->dp, h->dr, h->d_chunks, (int)h->chunks.size(), h->d_norms, h->d_hp, s);
     launch_opt_apply(h->dp, h->dr, h->da, h->d_chunks, (int)h->chunks.size(), h->d_norms, h->d_hp, clip, s);
     // BN moving statistics from the (all-reduced, hence grad_scale) batch statistics
     launch_state_update(h->ds, h->dr + h->P, h->d_sdescs, (int)h->sdescs.size(), h->d_hp, Bt, s);
+    stamp(h, 9, s);
   };
   int rc = run_captured(h, fkey("A:%d:%d", Bt, clip ? 1 : 0), s0, body);
   if (rc != MVAE_OK) return rc;
