@@ -202,7 +202,7 @@ def kernel_profile(step, nprof, act, workload):
 def pmc_traffic_table(workload):
     """The newest committed rocprofv3 PMC summary of this workload (tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
     separate passes, FETCH doubled per MI355X_MICROARCH.md), or None."""
-    for cand in ("round3_pmc_traffic_%s.json" % workload, "round2_pmc_traffic_%s.json" % workload):
+    for cand in ("round4_pmc_traffic_%s.json" % workload, "round3_pmc_traffic_%s.json" % workload, "round2_pmc_traffic_%s.json" % workload):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 return json.load(f), cand

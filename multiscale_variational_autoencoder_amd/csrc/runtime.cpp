@@ -978,9 +978,9 @@ constexpr bool debug_skip_scale(int) { return false; }
 // alone at the end.  (A rocprofv3 kernel trace suggests the opposite -- scale 0's queue idle for 0.4 - 0.6 ms behind each fork --
 // because the tracer serialises the dispatches of a graph replay on the host; the in-graph time stamps of MVAE_STAMPS=1 show
 // the unperturbed timeline, tools/stamps.py.)
-static bool scale0_first() {
-  static const bool v = [] { const char* e = getenv("MVAE_SCALE_ORDER"); return e ? atoi(e) != 0 : false; }();
-  return v;
+static bool scale0_first(int pass) {          // pass 1 = forward, 2 = backward; MVAE_SCALE_ORDER is a bit mask of the passes
+  static const int v = [] { const char* e = getenv("MVAE_SCALE_ORDER"); return e ? atoi(e) : 0; }();
+  return (v & pass) != 0;
 }
 // MVAE_STAMPS=1 (read at mvae_create): one-thread kernels that store the constant 100 MHz device clock at the forks, joins and
 // chain ends of a step, INSIDE the replayed graphs -- an unperturbed timeline (rocprofv3's kernel trace serialises the
@@ -1313,7 +1313,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
     fork_scales(h, s);
     PreOp none{nullptr, nullptr, nullptr};
     for (int ord = 0; ord < L; ++ord) {
-      const int si = scale0_first() ? ord : L - 1 - ord;
+      const int si = scale0_first(1) ? ord : L - 1 - ord;
       if (debug_skip_scale(si)) continue;
       hipStream_t ss = scale_stream(h, si, s);
       profiler().cur_scale = si;
@@ -1593,7 +1593,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
   // (Holding the smaller scales back until scale 0 reaches its MFMA-bound 5x5 convolutions, so that their HBM-bound work
   // would fill those windows, was measured: 5.88 .. 6.05 ms against 5.92 -- their chains are latency-bound and only move
   // the contention.  They start at the fork.)
-  for (int ord = 0; ord < L; ++ord) scale_half(scale0_first() ? ord : L - 1 - ord, phase);
+  for (int ord = 0; ord < L; ++ord) scale_half(scale0_first(2) ? ord : L - 1 - ord, phase);
   join_scales(h, s_main);
   stamp(h, 6, s_main);
   profiler().cur_scale = -1;
