@@ -411,239 +411,6 @@ __global__ void __launch_bounds__(256) k_se_bwd2(const float* __restrict__ ds1, 
   }
 }
 
-// =================================================================================================
-// Small batches (B <= kSeOneMaxB = 128): the whole squeeze-excite branch of a block in ONE launch per direction (round 4).
-// The two-launch form above exists because BatchNorm couples the batch rows; with at most 256 rows a single 1024-thread
-// workgroup holds every row tile in LDS and needs no second launch ([B, C] x [C, C] is 0.5 MFLOP at B = 128; 128 rows keep the
-// per-thread row values within the 128 registers a 1024-thread block leaves).  At the
-// notebook's batch (BASELINE config 1, B = 128) a step is a chain of ~375 graph nodes of which 120 were squeeze-excite
-// launches, and the step is bound by that chain's latency and by the host's node enqueue rate (tools/host_times.py: 1.87 ms
-// of host time per 2.10 ms step), not by bytes.
-//   thread (j = t % C, rq = t / C), G = 1024 / C row groups; rows rq, rq + G, ...
-// =================================================================================================
-constexpr int kSeOneMaxB = 128;
-
-template <int C>
-__global__ void __launch_bounds__(1024) k_se_fwd_one(const float* __restrict__ gap, const float* __restrict__ W0,
-                                                     const float* __restrict__ b0, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, const float* __restrict__ mov_mean,
-                                                     const float* __restrict__ mov_var, const float* __restrict__ W1,
-                                                     const float* __restrict__ b1, float* __restrict__ s0,
-                                                     float* __restrict__ xhat, float* __restrict__ invstd,
-                                                     float* __restrict__ ulin, float* __restrict__ gout,
-                                                     float* __restrict__ stat_mean, float* __restrict__ stat_var, int B, float eps,
-                                                     int training) {
-  constexpr int G = 1024 / C, RPT = kSeOneMaxB / G;
-  extern __shared__ __attribute__((aligned(16))) float se_lds[];
-  float* sA = se_lds;                        // [B][C] row tile: gap, then s1
-  float* red = sA + kSeOneMaxB * C;          // [G][C]
-  float* sstat = red + G * C;                // mean[C], inv[C]
-  const int j = threadIdx.x % C, rq = threadIdx.x / C;
-  float wcol[C];
-  se_load_wcol<C>(W0, j, wcol);
-  const float bias0 = b0[j], gm = gamma[j], bt = beta[j], bias1 = b1[j];
-  for (int idx = threadIdx.x; idx < B * C / 4; idx += 1024)
-    reinterpret_cast<float4*>(sA)[idx] = reinterpret_cast<const float4*>(gap)[idx];
-  __syncthreads();
-  float v[RPT];
-  float sum = 0.f;
-#pragma unroll
-  for (int q = 0; q < RPT; ++q) {
-    const int r = rq + q * G;
-    float a = bias0;
-    if (r < B) {
-#pragma unroll
-      for (int k0 = 0; k0 < C; k0 += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(&sA[r * C + k0]);
-        a += x.x * wcol[k0] + x.y * wcol[k0 + 1] + x.z * wcol[k0 + 2] + x.w * wcol[k0 + 3];
-      }
-      a = fmaxf(a, 0.f);
-      s0[(int64_t)r * C + j] = a;
-      sum += a;
-    }
-    v[q] = a;
-  }
-  float mu, inv;
-  if (training) {
-    red[rq * C + j] = sum;
-    __syncthreads();
-    if (rq == 0) {
-      float t = 0.f;
-      for (int g = 0; g < G; ++g) t += red[g * C + j];
-      sstat[j] = t / (float)B;
-    }
-    __syncthreads();
-    mu = sstat[j];
-    float m2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-      const float d = v[q] - mu;
-      if (rq + q * G < B) m2 += d * d;
-    }
-    __syncthreads();
-    red[rq * C + j] = m2;
-    __syncthreads();
-    if (rq == 0) {
-      float t = 0.f;
-      for (int g = 0; g < G; ++g) t += red[g * C + j];
-      const float var = t / (float)B;
-      sstat[C + j] = rsqrtf(var + eps);
-      stat_mean[j] = mu; stat_var[j] = var;
-    }
-    __syncthreads();
-    inv = sstat[C + j];
-  } else {
-    mu = mov_mean[j];
-    inv = rsqrtf(mov_var[j] + eps);
-  }
-  if (rq == 0) invstd[j] = inv;
-  se_load_wcol<C>(W1, j, wcol);
-  __syncthreads();                           // every thread is done reading the gap tile
-#pragma unroll
-  for (int q = 0; q < RPT; ++q) {
-    const int r = rq + q * G;
-    if (r < B) {
-      const float xh = (v[q] - mu) * inv;
-      xhat[(int64_t)r * C + j] = xh;
-      sA[r * C + j] = xh * gm + bt;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < RPT; ++q) {
-    const int r = rq + q * G;
-    if (r < B) {
-      float a = bias1;
-#pragma unroll
-      for (int k0 = 0; k0 < C; k0 += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(&sA[r * C + k0]);
-        a += x.x * wcol[k0] + x.y * wcol[k0 + 1] + x.z * wcol[k0 + 2] + x.w * wcol[k0 + 3];
-      }
-      ulin[(int64_t)r * C + j] = a;
-      gout[(int64_t)r * C + j] = se_hsig(a);
-    }
-  }
-}
-
-// backward in one launch: du = dg hsig'(u); dW1, db1; ds1 = du W1^T; BatchNorm backward over the batch; ReLU mask; dW0, db0;
-// dgap = dv W0^T; dgamma, dbeta.  Weight gradients: thread (j, kq = rq) owns dW[k = kq + G q][j], q < C / G, summed over all
-// rows from the LDS tiles; one atomic per entry (a single adder: the result is deterministic).
-template <int C>
-__global__ void __launch_bounds__(1024) k_se_bwd_one(const float* __restrict__ dg, const float* __restrict__ ulin,
-                                                     const float* __restrict__ xhat, const float* __restrict__ invstd,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     const float* __restrict__ s0, const float* __restrict__ gap,
-                                                     const float* __restrict__ W1, const float* __restrict__ W0,
-                                                     float* __restrict__ dgap, float* __restrict__ dW1, float* __restrict__ db1,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dW0,
-                                                     float* __restrict__ db0, int B, int dslots, int64_t dstride) {
-  constexpr int G = 1024 / C, RPT = kSeOneMaxB / G, KPT = C / G > 0 ? C / G : 1;
-  extern __shared__ __attribute__((aligned(16))) float se_lds[];
-  float* sV = se_lds;                        // [B][C] gradient at a Dense output
-  float* sX = sV + kSeOneMaxB * C;           // [B][C] that Dense layer's input
-  float* sW = sX + kSeOneMaxB * C;           // [C][C + 1]
-  float* red = sW + C * (C + 1);             // [2][G][C]
-  float* stot = red + 2 * G * C;             // [2][C]
-  const int j = threadIdx.x % C, rq = threadIdx.x / C;
-  const float gm = gamma[j], bt = beta[j];
-  float xh[RPT];
-#pragma unroll
-  for (int q = 0; q < RPT; ++q) {
-    const int r = rq + q * G;
-    xh[q] = 0.f;
-    if (r < B) {
-      const int64_t o = (int64_t)r * C + j;
-      float gsum = 0.f;
-      for (int k = 0; k < dslots; ++k) gsum += dg[o + (int64_t)k * dstride];
-      xh[q] = xhat[o];
-      sV[r * C + j] = gsum * se_hsig_grad(ulin[o]);
-      sX[r * C + j] = xh[q] * gm + bt;
-    }
-  }
-  for (int idx = threadIdx.x; idx < C * C; idx += 1024) sW[(idx / C) * (C + 1) + idx % C] = W1[idx];
-  __syncthreads();
-  // ---- Dense 1 backward
-  auto dense_bwd = [&](float (&dx)[RPT], float* __restrict__ dW, float* __restrict__ db) {
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-      const int r = rq + q * G;
-      float a = 0.f;
-      if (r < B)
-        for (int n0 = 0; n0 < C; n0 += 4) {
-          const float4 vv = *reinterpret_cast<const float4*>(&sV[r * C + n0]);
-          a += vv.x * sW[j * (C + 1) + n0] + vv.y * sW[j * (C + 1) + n0 + 1] + vv.z * sW[j * (C + 1) + n0 + 2] +
-               vv.w * sW[j * (C + 1) + n0 + 3];
-        }
-      dx[q] = a;                                            // dx[r][k = j] = sum_n sV[r][n] W[k = j][n]
-    }
-    if (rq < C) {                                           // G may exceed C (C = 32: 32 row groups, all used: KPT = 1)
-      float gw[KPT];
-#pragma unroll
-      for (int q = 0; q < KPT; ++q) gw[q] = 0.f;
-      float gb = 0.f;
-      const int kq = rq % (C / KPT);
-      for (int r = 0; r < B; ++r) {
-        const float vv = sV[r * C + j];
-        gb += vv;
-#pragma unroll
-        for (int q = 0; q < KPT; ++q) gw[q] += sX[r * C + kq + (C / KPT) * q] * vv;
-      }
-#pragma unroll
-      for (int q = 0; q < KPT; ++q) atomicAdd(&dW[(kq + (C / KPT) * q) * C + j], gw[q]);
-      if (rq == 0) atomicAdd(&db[j], gb);
-    }
-  };
-  float dx[RPT];
-  dense_bwd(dx, dW1, db1);
-  // ---- BatchNorm backward with batch statistics
-  float p1 = 0.f, p2 = 0.f;
-#pragma unroll
-  for (int q = 0; q < RPT; ++q)
-    if (rq + q * G < B) { p1 += dx[q]; p2 += dx[q] * xh[q]; }
-  red[rq * C + j] = p1;
-  red[G * C + rq * C + j] = p2;
-  __syncthreads();                            // (also: every thread is done with sV / sX / sW of Dense 1)
-  if (rq < 2) {
-    float t = 0.f;
-    for (int g = 0; g < G; ++g) t += red[rq * G * C + g * C + j];
-    stot[rq * C + j] = t;
-    if (rq == 0) dbeta[j] += t; else dgamma[j] += t;
-  }
-  for (int idx = threadIdx.x; idx < C * C; idx += 1024) sW[(idx / C) * (C + 1) + idx % C] = W0[idx];
-  __syncthreads();
-  const float inv_b = 1.0f / (float)B;
-  const float md = stot[j] * inv_b, mdx = stot[C + j] * inv_b, gi = gm * invstd[j];
-#pragma unroll
-  for (int q = 0; q < RPT; ++q) {
-    const int r = rq + q * G;
-    if (r < B) {
-      const int64_t o = (int64_t)r * C + j;
-      const float vv = gi * (dx[q] - md - xh[q] * mdx);
-      sV[r * C + j] = s0[o] > 0.f ? vv : 0.f;
-      sX[r * C + j] = gap[o];
-    }
-  }
-  __syncthreads();
-  dense_bwd(dx, dW0, db0);
-#pragma unroll
-  for (int q = 0; q < RPT; ++q) {
-    const int r = rq + q * G;
-    if (r < B) dgap[(int64_t)r * C + j] = dx[q];
-  }
-}
-
-static bool se_one_enabled(int B) {
-  static const int on = [] { const char* e = getenv("MVAE_SE_ONE"); return e ? atoi(e) : 1; }();
-  return on && B <= kSeOneMaxB && !det_mode();
-}
-template <int C>
-static bool se_one_attr() {
-  static const bool ok =
-      hipFuncSetAttribute((const void*)k_se_fwd_one<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-      hipFuncSetAttribute((const void*)k_se_bwd_one<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-  return ok;
-}
-
 // rows per block: 16 keeps each block's Dense work at a few hundred FMAs per thread; at most 64 blocks to merge
 static inline int se_rows_per_block(int B) { return (B + 15) / 16 <= 64 ? 16 : kSeRowsMax; }
 int se_max_blocks(int max_batch) {
@@ -665,16 +432,6 @@ bool launch_se_forward(const float* gap, const float* W0, const float* b0, const
                        float* xhat, float* invstd, float* ulin, float* g, float* stat_mean, float* stat_var,
                        float* part, int B, int C, float eps, int training, hipStream_t s) {
   if ((C != 32 && C != 64) || B > 64 * kSeRowsMax) return false;
-  if (se_one_enabled(B) && (C == 64 ? se_one_attr<64>() : se_one_attr<32>())) {
-    ProfScope ps("se_fwd_one", 4.0 * (5.0 * B * C + 2.0 * C * C), 4.0 * B * C * C, s);
-    const int G = 1024 / C;
-    const size_t lds = sizeof(float) * ((size_t)kSeOneMaxB * C + (size_t)G * C + 2 * C);
-    if (C == 64) hipLaunchKernelGGL(k_se_fwd_one<64>, dim3(1), dim3(1024), lds, s, gap, W0, b0, gamma, beta, mov_mean, mov_var, W1, b1,
-                                    s0, xhat, invstd, ulin, g, stat_mean, stat_var, B, eps, training);
-    else hipLaunchKernelGGL(k_se_fwd_one<32>, dim3(1), dim3(1024), lds, s, gap, W0, b0, gamma, beta, mov_mean, mov_var, W1, b1, s0,
-                            xhat, invstd, ulin, g, stat_mean, stat_var, B, eps, training);
-    return true;
-  }
   const int RB = se_rows_per_block(B), nblk = (B + RB - 1) / RB;
   ProfScope ps("se_fwd", 4.0 * (5.0 * B * C + 2.0 * C * C), 4.0 * B * C * C, s);
   MVAE_SE_DISPATCH(k_se_fwd1, gap, W0, b0, s0, part, B, RB);
@@ -689,18 +446,6 @@ bool launch_se_backward(const float* dg, const float* ulin, const float* xhat, c
                         float* db0, float* part, int B, int C, GradSlots sl, int dslots, int64_t dstride,
                         hipStream_t s) {
   if ((C != 32 && C != 64) || B > 64 * kSeRowsMax) return false;
-  if (se_one_enabled(B) && (C == 64 ? se_one_attr<64>() : se_one_attr<32>())) {
-    ProfScope ps("se_bwd_one", 4.0 * (8.0 * B * C + 2.0 * C * C), 8.0 * B * C * C, s);
-    const int G = 1024 / C;
-    const size_t lds = sizeof(float) * ((size_t)2 * kSeOneMaxB * C + (size_t)C * (C + 1) + 2 * (size_t)G * C + 2 * C);
-    const int ds = dslots < 1 ? 1 : dslots;
-    // (one block: its atomics go to slot copy 0 of the gradient arena)
-    if (C == 64) hipLaunchKernelGGL(k_se_bwd_one<64>, dim3(1), dim3(1024), lds, s, dg, ulin, xhat, invstd, gamma, beta, s0, gap, W1, W0,
-                                    dgap, sl.at(dW1), sl.at(db1), dgamma, dbeta, sl.at(dW0), sl.at(db0), B, ds, dstride);
-    else hipLaunchKernelGGL(k_se_bwd_one<32>, dim3(1), dim3(1024), lds, s, dg, ulin, xhat, invstd, gamma, beta, s0, gap, W1, W0, dgap,
-                            sl.at(dW1), sl.at(db1), dgamma, dbeta, sl.at(dW0), sl.at(db0), B, ds, dstride);
-    return true;
-  }
   const int RB = se_rows_per_block(B), nblk = (B + RB - 1) / RB;
   ProfScope ps("se_bwd", 4.0 * (8.0 * B * C + 2.0 * C * C), 8.0 * B * C * C, s);
   MVAE_SE_DISPATCH(k_se_bwd1, dg, ulin, xhat, gamma, beta, W1, ds1, sl.at(dW1), sl.at(db1), part, B, RB, sl.count(),

@@ -143,12 +143,9 @@ def _subprocess_case(name, B, tag, env):
     return r.stdout
 
 
-# se_one: batches up to 128 run the squeeze-excite branch as ONE launch per direction (k_se_fwd_one / k_se_bwd_one, round 4), so
-# the in-process cases above all take that path; "0" keeps the two-launch kernels -- the headline's, B = 512 -- under the oracle.
-@pytest.mark.parametrize("name,B,det,se_one", [("c32nb", 20, "0", "0"), ("c64nb", 20, "0", "0"), ("c32nb", 33, "0", "1"),
-                                               ("c32nb", 20, "1", "1")])
-def test_multi_image_blocks_parity(name, B, det, se_one):
-    env = dict(MULTI_IMAGE_ENV, MVAE_DETERMINISTIC=det, MVAE_SE_ONE=se_one)
+@pytest.mark.parametrize("name,B,det", [("c32nb", 20, "0"), ("c64nb", 20, "0"), ("c32nb", 33, "0"), ("c32nb", 20, "1")])
+def test_multi_image_blocks_parity(name, B, det):
+    env = dict(MULTI_IMAGE_ENV, MVAE_DETERMINISTIC=det)
     out = _subprocess_case(name, B, "multi_%s_b%d_det%s" % (name, B, det), env)
     assert "fused launches: fwd" in out and "images per block" in out, out[-2000:]
 
