@@ -607,26 +607,33 @@ struct ConvFRowsS {
         __builtin_amdgcn_sched_barrier(0);
         const char* w = sW[t & 1];
         const int rho = rho0 + ((kw & 1) * HALF + (kw >> 1)) * R;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-          bf16x8 xa[3];
+        // fragment reads run ONE MFMA group ahead of their MFMAs (two register sets): with the reads of a group issued right
+        // in front of its own MFMAs every group opened with an exposed LDS round trip (tools/isa_flow.py: R128x3 wait M ...)
+        constexpr int G = KK * NT;
+        bf16x8 xa[2][3], wb[2][3];
+        auto load_x = [&](int kk, bf16x8 (&d)[3]) {
           const int ao = tile_off<KC>(rho, 2 * kk + h);
 #pragma unroll
-          for (int p = 0; p < 3; ++p) xa[p] = as_frag(*reinterpret_cast<const u32x4*>(myA + p * PLANE_A + ao));
+          for (int p = 0; p < 3; ++p) d[p] = as_frag(*reinterpret_cast<const u32x4*>(myA + p * PLANE_A + ao));
+        };
+        auto load_w = [&](int kk, int nt, bf16x8 (&d)[3]) {
+          const int wo = wrow_off<KC>(nt * 32 + i, 2 * kk + h);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            bf16x8 wb[3];
-            const int wo = wrow_off<KC>(nt * 32 + i, 2 * kk + h);
+          for (int p = 0; p < 3; ++p) d[p] = as_frag(*reinterpret_cast<const u32x4*>(w + p * PLANE_W + wo));
+        };
+        load_x(0, xa[0]);
+        load_w(0, 0, wb[0]);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wb[p] = as_frag(*reinterpret_cast<const u32x4*>(w + p * PLANE_W + wo));
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[2], wb[0], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1], wb[1], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], wb[2], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1], wb[0], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], wb[1], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0], wb[0], acc[nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int gi = 0; gi < G; ++gi) {
+          const int kk = gi / NT, nt = gi % NT;
+          if (gi + 1 < G) {
+            const int kk2 = (gi + 1) / NT, nt2 = (gi + 1) % NT;
+            if (kk2 != kk) load_x(kk2, xa[kk2 & 1]);
+            load_w(kk2, nt2, wb[(gi + 1) & 1]);
           }
+          __builtin_amdgcn_sched_barrier(0);
+          MVAE_SPLIT6(acc[nt], xa[kk & 1], wb[gi & 1]);
+          __builtin_amdgcn_sched_barrier(0);
         }
         if (t + 1 < 25) store_w((t + 1) % PF, (t + 1) & 1);
         if (kw == 4 && kh + 1 < 5) stage_a();                 // wave-private region: this wave's reads of it are done
