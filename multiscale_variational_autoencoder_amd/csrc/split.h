@@ -38,9 +38,10 @@ __device__ __host__ __forceinline__ int wrow_off(int n, int chunk) { return row_
 __device__ __forceinline__ unsigned hi16_pair(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 // four float32 -> three bf16 planes (4 bf16 = 8 bytes each), exact: x = p1 + p2 + p3.  Per pair of floats: one v_perm_b32
-// packs the two high halves (the truncated bf16), two v_and_b32 rebuild them as floats, one v_pk_add_f32 takes both
-// residuals -- 9 VALU instructions per pair for the three planes (the split is this kernel's VALU load: ~100 instructions
-// per tap next to its 24 MFMAs).
+// packs the two high halves (the truncated bf16), two v_and_b32 rebuild them as floats, two v_sub_f32 take the residuals
+// (the library is built WITHOUT packed-float32 instructions, DESIGN.md 5c: the f32x2 arithmetic below compiles to scalar
+// v_sub_f32, never v_pk_add_f32) -- ~10 VALU instructions per pair for the three planes (the split is this kernel's VALU
+// load: ~100 instructions per tap next to its 24 MFMAs).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const u32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
   unsigned r1[4], r2[4];
