@@ -1041,6 +1041,153 @@ __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ i
 }
 
 // =================================================================================================
+// F-form (5 x 5, stride 2, SAME) in bf16 with the input rows of a KERNEL ROW staged in LDS once (round 4; the bf16
+// counterpart of k_convf_rows_s, kernels_split.hip).  k16_taps<.., TFORM = false> gathers a wave's 32 input pixels once per
+// tap: 25 gather -> LDS -> fragment phases per tile, each a dependent chain, and every input pixel crosses the fabric 2 - 4
+// times (PMC, round 2/3).  Here a wave loads, per kernel row kh, the R = 32 / COLS input row segments its 32 output pixels
+// read through the five kw taps (2 COLS + 3 pixels each), once; the five taps of the row read their B fragments from that
+// LDS region at pixel 2 c + kw (even and odd segment pixels stored apart, output row minor: row index ((q & 1) HALF +
+// (q >> 1)) R + j): 5 load / store phases per tile instead of 25, 2.3x fewer gathered bytes.  All 25 weight slices stay in
+// LDS (100 KB), which leaves room for NW = 6 (KC = 64) or 12 (KC = 32) waves of staged rows.
+// =================================================================================================
+static int cus16();
+template <int C>
+__device__ __forceinline__ int rtile_off(int row, int chunk) {         // split.h's row_off: conflict-free for rows at stride R
+  if constexpr (C == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  else return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+template <int KC, int NC, int COLS, int NW>
+__global__ void __launch_bounds__(64 * NW) k16_taps_fr(const bf16_t* __restrict__ in, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, bf16_t* __restrict__ out, ConvGeom g,
+                                                     unsigned in_bytes, int tiles_per_wave) {
+  constexpr int NT = NC / 32, KK = KC / 16;
+  constexpr int CPP = KC / 8, PPI = 64 / CPP;                        // 16-byte chunks per pixel, pixels per load instruction
+  constexpr int R = 32 / COLS, SEG = 2 * COLS + 3, HALF = COLS + 2, NPX = R * SEG;
+  constexpr int NL = (NPX + PPI - 1) / PPI;
+  constexpr int ABYTES = ((NPX + 7) / 8 * 8) * KC * 2;
+  extern __shared__ __attribute__((aligned(16))) char fr_lds[];
+  char* sW = fr_lds;                                                 // [25][NC][KC] bf16
+  char* sA = fr_lds + 25 * NC * KC * 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  char* myA = sA + wave * ABYTES;
+  const int CH = g.OH, CW = g.OW;
+  const unsigned Mc = (unsigned)(g.B * CH * CW);
+  // all 25 weight slices -> LDS, bf16, [tap][n][k] from the Keras HWIO array W[tap][k][n]
+  for (int idx = threadIdx.x; idx < 25 * NC * KC; idx += 64 * NW) {
+    const int tap = idx / (NC * KC), rem = idx % (NC * KC);
+    const int k = rem / NC, n = rem % NC;
+    const float v = W[idx];
+    const int off = tap * NC * KC * 2 + n * KC * 2 + (((k >> 3) ^ ((KC == 32 ? n >> 1 : n) & (KC / 8 - 1))) << 4) + (k & 7) * 2;
+    *reinterpret_cast<uint16_t*>(sW + off) = (uint16_t)(pack_bf16(v, 0.f) & 0xFFFFu);
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(in), 0, (int)in_bytes, 0x00020000);
+  const int lp = lane / CPP, ch = lane % CPP;
+  const unsigned row_bytes = (unsigned)(g.IW * KC * 2);
+  const int rho0 = (r % COLS) * R + (r / COLS);
+  const unsigned wtile0 = ((unsigned)blockIdx.x * (unsigned)NW + wave) * (unsigned)tiles_per_wave;
+  for (int ti = 0; ti < tiles_per_wave; ++ti) {
+    const unsigned p0 = (wtile0 + ti) * 32u;
+    if (p0 >= Mc) break;                                             // wave-uniform
+    unsigned base[NL], rmask[NL];
+    int lds_o[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int sidx = u * PPI + lp;
+      const int j = sidx / SEG, q = sidx - j * SEG;
+      const unsigned pj = p0 + (unsigned)(j * COLS);
+      const bool live = sidx < NPX && pj < Mc;
+      const unsigned pp = live ? pj : 0u;
+      const int ox0 = (int)(pp % (unsigned)CW);
+      const unsigned t2 = pp / (unsigned)CW;
+      const int oy = (int)(t2 % (unsigned)CH), b = (int)(t2 / (unsigned)CH);
+      const int x = ox0 * 2 - g.PL + q, y0 = oy * 2 - g.PT;
+      unsigned m = (live && (unsigned)x < (unsigned)g.IW) ? 0u : 0x1Fu;
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh)
+        if ((unsigned)(y0 + kh) >= (unsigned)g.IH) m |= 1u << kh;
+      rmask[u] = m;
+      base[u] = (unsigned)(((b * g.IH + y0) * g.IW + x) * KC + ch * 8) * 2u;
+      lds_o[u] = rtile_off<KC>(((q & 1) * HALF + (q >> 1)) * R + j, ch);
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+    u32x4 xc[NL], xn[NL];
+    auto fetch = [&](int kh, u32x4 (&dst)[NL]) {
+#pragma unroll
+      for (int u = 0; u < NL; ++u)
+        dst[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (rmask[u] >> kh) & 1u ? 0x80000000u : base[u] + (unsigned)kh * row_bytes, 0, 0);
+    };
+    fetch(0, xc);
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh) {
+      if (kh + 1 < 5) fetch(kh + 1, xn);                             // next kernel row's segments in flight under this row's taps
+      WAVE_LDS_SYNC16();                                             // the previous row's fragment reads are done
+#pragma unroll
+      for (int u = 0; u < NL; ++u)
+        if (u * PPI + lp < NPX) *reinterpret_cast<u32x4*>(myA + lds_o[u]) = xc[u];
+      WAVE_LDS_SYNC16();
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        const int rho = rho0 + ((kw & 1) * HALF + (kw >> 1)) * R;
+        const char* wt = sW + (kh * 5 + kw) * NC * KC * 2;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          const bf16x8 xb = as_frag(*reinterpret_cast<const u32x4*>(myA + rtile_off<KC>(rho, 2 * kk + h)));
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + r;
+            const bf16x8 wa = as_frag(*reinterpret_cast<const u32x4*>(wt + n * KC * 2 + (((2 * kk + h) ^ ((KC == 32 ? n >> 1 : n) & (KC / 8 - 1))) << 4)));
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[nt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NL; ++u) xc[u] = xn[u];
+    }
+    // ---- epilogue (as k16_taps, F-form): bias, pack, 16-byte stores
+    const unsigned p = p0 + r;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      uint2 pk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (bias) bq = *reinterpret_cast<const f32x4*>(bias + nt * 32 + 8 * q + 4 * h);
+        f32x4 v = {acc[nt][4 * q] + bq[0], acc[nt][4 * q + 1] + bq[1], acc[nt][4 * q + 2] + bq[2], acc[nt][4 * q + 3] + bq[3]};
+        pk[q] = pack4(v);
+      }
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        uint2 a = pk[2 * pp], bb = pk[2 * pp + 1];
+        auto s0 = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
+        if (p < Mc) *reinterpret_cast<u32x4*>(out + (int64_t)p * NC + nt * 32 + 16 * pp + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+    }
+  }
+}
+template <int KC, int NC, int COLS, int NW>
+static bool launch16_taps_fr(const void* in, const float* w, const float* bias, void* out, const ConvGeom& g, unsigned in_bytes,
+                             int64_t tiles, hipStream_t s) {
+  constexpr int R = 32 / COLS, NPX = R * (2 * COLS + 3), ABYTES = ((NPX + 7) / 8 * 8) * KC * 2;
+  constexpr int lds = 25 * NC * KC * 2 + NW * ABYTES;
+  static_assert(lds <= 160 * 1024, "staged rows + weight slices do not fit the LDS");
+  static const bool attr = hipFuncSetAttribute((const void*)k16_taps_fr<KC, NC, COLS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               lds) == hipSuccess;
+  if (!attr) return false;
+  int64_t waves = (int64_t)NW * cus16();
+  if (waves > tiles) waves = tiles;
+  const int tpw = (int)((tiles + waves - 1) / waves);
+  const unsigned gx = (unsigned)(((tiles + tpw - 1) / tpw + NW - 1) / NW);
+  hipLaunchKernelGGL((k16_taps_fr<KC, NC, COLS, NW>), dim3(gx), dim3(64 * NW), lds, s, (const bf16_t*)in, w, bias, (bf16_t*)out, g,
+                     in_bytes, tpw);
+  return true;
+}
+
+// =================================================================================================
 // Weight gradient of a strided SAME convolution (F-form coordinates), bf16 storage:
 //   dW[tap][ci][co] += sum_m big[gather(m, tap)][ci] * small[m][co] ;  db[co] += sum_m small[m][co]
 // One block per (row chunk, kernel row kh) as k_wgrad_taprow: the TG = KW taps of the row share the staged `small` tile
@@ -1601,6 +1748,20 @@ bool launch16_taps(bool transposed, const void* in, const float* w, const float*
                          in_bytes, tpw_m, nullptr, nullptr, nullptr);
     }
     return true;
+  }
+  // F-form with the input rows of a kernel row staged in LDS (k16_taps_fr): 5 x 5, stride 2, output width 4 / 8 / 16 / 32k
+  static const bool rows_on = [] { const char* e = getenv("MVAE_CONVF_ROWS16"); return e ? atoi(e) != 0 : true; }();
+  if (!transposed && rows_on && g.KH == 5 && g.KW == 5 && g.SH == 2 && g.SW == 2 &&
+      (g.OW % 32 == 0 || g.OW == 16 || g.OW == 8 || g.OW == 4)) {
+    const int cols = g.OW >= 32 ? 32 : g.OW;
+    bool ok = false;
+#define MVAE_FR(A, B_, NWV) (cols == 32 ? launch16_taps_fr<A, B_, 32, NWV>(in, w, bias, out, g, in_bytes, tiles, s)        \
+                             : cols == 16 ? launch16_taps_fr<A, B_, 16, NWV>(in, w, bias, out, g, in_bytes, tiles, s)      \
+                             : cols == 8 ? launch16_taps_fr<A, B_, 8, NWV>(in, w, bias, out, g, in_bytes, tiles, s)        \
+                                         : launch16_taps_fr<A, B_, 4, NWV>(in, w, bias, out, g, in_bytes, tiles, s))
+    if (KC == 32) ok = MVAE_FR(32, 64, 10); else ok = MVAE_FR(64, 32, 5);
+#undef MVAE_FR
+    if (ok) return true;
   }
   static const bool chain_on = [] { const char* e = getenv("MVAE_FUSE_PW_CHAIN"); return e ? atoi(e) != 0 : true; }();
   if (KC == 32 && NC == 64 && transposed && w2 && out2 && chain_on) {
