@@ -1338,6 +1338,151 @@ __global__ void __launch_bounds__(256, 2) k16_wgrad(const bf16_t* __restrict__ b
   }
 }
 
+// =================================================================================================
+// 5 x 5 stride-2 weight gradient in bf16 with the `big` operand's row segment staged in LDS once per tile (round 4).
+// k16_wgrad<*, *, 5> gathers the 32 input pixels of a tile once per tap: five gather -> LDS -> transposed-fragment phases per
+// tile.  With OW a multiple of 32 a tile is 32 consecutive pixels of ONE output row, and the five kw taps of the block's
+// kernel row read the same input row at columns 2 c + kw: the 67-pixel segment is loaded once, even and odd pixels stored
+// apart (row = (q & 1) 34 + (q >> 1)), and tap kw reads its transposed fragments at row offset (kw & 1) 34 + (kw >> 1).
+// 2.4x fewer gathered bytes and LDS writes; same block decomposition (row chunk x kernel row, XCD-aware grid) and epilogue.
+// =================================================================================================
+template <int C>
+__device__ __forceinline__ bf16x8 frag_cols_at(const char* tile, int lane, int ct, int s, int roff) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int c0 = ct * 32 + 16 * (g & 1) + 4 * p;
+  const int rb = roff + 16 * s + 8 * (g >> 1);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int o0 = tile_off<C>(rb + q, c0 >> 3) + (c0 & 7) * 2;
+  const int o1 = tile_off<C>(rb + 4 + q, c0 >> 3) + (c0 & 7) * 2;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o1));
+  s16x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, f);
+}
+template <int CI, int CO>
+__global__ void __launch_bounds__(256, 2) k16_wgrad_seg(const bf16_t* __restrict__ big, const bf16_t* __restrict__ small,
+                                                        float* __restrict__ dW, float* __restrict__ db, ConvGeom g, int64_t M,
+                                                        int64_t rows_per_block) {
+  constexpr int KT = CI / 32, NT = CO / 32, TG = 5;
+  constexpr int SEG = 67, HALF = 34, SROWS = 72;                     // staged pixels, even-pixel rows, rows reserved
+  constexpr int TB = SROWS * CI * 2, TS = 32 * CO * 2, TILE = TB + TS;
+  __shared__ __attribute__((aligned(16))) char lds[(4 * TILE > CI * CO * 4) ? 4 * TILE : CI * CO * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  char* tb = lds + wave * TILE;
+  char* ts = tb + TB;
+  const int xcd = blockIdx.x & 7, kh = (blockIdx.x >> 3) % g.KH;
+  const uint32_t chunk = ((blockIdx.x >> 3) / g.KH) * 8u + xcd;
+  if ((int64_t)chunk * rows_per_block >= M) return;
+  f32x16 acc[TG][KT][NT];
+#pragma unroll
+  for (int t = 0; t < TG; ++t)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[t][kt][nt] = zero16();
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+  uint32_t m_begin = chunk * (uint32_t)rows_per_block;
+  uint32_t m_end = m_begin + (uint32_t)rows_per_block;
+  if (m_end > (uint32_t)M) m_end = (uint32_t)M;
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(big), 0,
+      (int)((unsigned)g.B * g.IH * g.IW * CI * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(small), 0,
+      (int)((unsigned)M * CO * 2u), 0x00020000);
+  constexpr int CPX = CI / 8, CPG = CO / 8;                          // 16-byte chunks per pixel
+  constexpr int PPI = 64 / CPX, NLB = (SEG + PPI - 1) / PPI, LG = CO / 16;
+  const int lpx = lane / CPX, chx = lane % CPX;
+  u32x4 xq[NLB], gq[LG];
+  auto load_seg = [&](uint32_t row0) {                               // the tile's input row segment: 67 pixels from column 2 ow0 - PL
+    const uint32_t ow0 = row0 % (uint32_t)g.OW, t2 = row0 / (uint32_t)g.OW;
+    const int oh = (int)(t2 % (uint32_t)g.OH), bi = (int)(t2 / (uint32_t)g.OH);
+    const int yy = oh * g.SH + kh - g.PT, x0 = (int)ow0 * g.SW - g.PL;
+    const bool rowok = row0 < m_end && (unsigned)yy < (unsigned)g.IH;
+    const unsigned rbase = (unsigned)(((bi * g.IH + yy) * g.IW + x0) * CI) * 2u;
+#pragma unroll
+    for (int u = 0; u < NLB; ++u) {
+      const int q = u * PPI + lpx;
+      const bool ok = rowok && q < SEG && (unsigned)(x0 + q) < (unsigned)g.IW;
+      xq[u] = __builtin_amdgcn_raw_buffer_load_b128(brs, ok ? rbase + (unsigned)((q * CI + chx * 8) * 2) : 0x80000000u, 0, 0);
+    }
+  };
+  auto load_small = [&](uint32_t row0) {
+#pragma unroll
+    for (int j = 0; j < LG; ++j) {
+      const int c = j * 64 + lane, pr = c / CPG, ch = c % CPG;
+      const uint32_t mm = row0 + pr;
+      gq[j] = __builtin_amdgcn_raw_buffer_load_b128(srs, mm < m_end ? (mm * CO + ch * 8) * 2u : 0x80000000u, 0, 0);
+    }
+  };
+  uint32_t row0 = m_begin + wave * 32;
+  if (row0 < m_end) { load_small(row0); load_seg(row0); }
+  for (; row0 < m_end; row0 += 4 * 32) {
+    WAVE_LDS_SYNC16();                              // the previous tile's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < LG; ++j) {
+      const int c = j * 64 + lane;
+      *reinterpret_cast<u32x4*>(ts + tile_off<CO>(c / CPG, c % CPG)) = gq[j];
+    }
+#pragma unroll
+    for (int u = 0; u < NLB; ++u) {
+      const int q = u * PPI + lpx;
+      if (q < SEG) *reinterpret_cast<u32x4*>(tb + tile_off<CI>((q & 1) * HALF + (q >> 1), chx)) = xq[u];
+    }
+    WAVE_LDS_SYNC16();
+    if (row0 + 4 * 32 < m_end) { load_small(row0 + 4 * 32); load_seg(row0 + 4 * 32); }     // next tile in flight under the MFMAs
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 fs[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { fs[nt] = frag_cols<CO>(ts, lane, nt, s); bsum[nt] = frag_sum(fs[nt], bsum[nt]); }
+#pragma unroll
+      for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const bf16x8 fb = frag_cols_at<CI>(tb, lane, kt, s, (t & 1) * HALF + (t >> 1));
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[t][kt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fs[nt], acc[t][kt][nt], 0, 0, 0);
+        }
+    }
+  }
+  float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int t = 0; t < TG; ++t) {
+    for (int wv = 0; wv < 4; ++wv) {
+      __syncthreads();
+      if (wave == wv) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int ci = kt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+              const int idx = ci * CO + nt * 32 + r;
+              red[idx] = (wv == 0 ? 0.f : red[idx]) + acc[t][kt][nt][reg];
+            }
+      }
+    }
+    __syncthreads();
+    float* dWt = dW + (int64_t)(kh * g.KW + t) * CI * CO;
+    for (int idx = threadIdx.x; idx < CI * CO; idx += 256) atomicAdd(&dWt[idx], red[idx]);
+  }
+  if (db != nullptr && kh == 0) {
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float b = bsum[nt] + __shfl_xor(bsum[nt], 32, 64);
+      if (h == 0) red[wave * CO + nt * 32 + r] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < CO)
+      atomicAdd(&db[threadIdx.x], red[threadIdx.x] + red[CO + threadIdx.x] + red[2 * CO + threadIdx.x] + red[3 * CO + threadIdx.x]);
+  }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------------
 static int cus16() {
   static const int v = [] { const char* e = getenv("MVAE_BIG_CUS16"); int n = e ? atoi(e) : 256; return n < 8 ? 8 : (n > 256 ? 256 : n); }();
@@ -1795,6 +1940,15 @@ bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, co
 #define MVAE_W16(A, B_, TG)                                                                                           \
   hipLaunchKernelGGL((k16_wgrad<A, B_, TG>), dim3(groups * 8u * g.KH), dim3(256), 0, s, (const bf16_t*)big,           \
                      (const bf16_t*)small, sl.at(dW), sl.at(db), g, M, rpb, sl.count(), sl.stride)
+  // 5 x 5, stride 2, SAME, output rows of whole 32-pixel tiles: the input row segment staged once per tile (k16_wgrad_seg)
+  static const bool seg_on = [] { const char* e = getenv("MVAE_WGRAD_SEG16"); return e ? atoi(e) != 0 : true; }();
+  if (!pointwise && seg_on && g.KH == 5 && g.SH == 2 && g.SW == 2 && g.OW % 32 == 0 && rpb % 32 == 0) {
+    if (g.CI == 32) hipLaunchKernelGGL((k16_wgrad_seg<32, 64>), dim3(groups * 8u * g.KH), dim3(256), 0, s, (const bf16_t*)big,
+                                       (const bf16_t*)small, dW, db, g, M, rpb);
+    else hipLaunchKernelGGL((k16_wgrad_seg<64, 32>), dim3(groups * 8u * g.KH), dim3(256), 0, s, (const bf16_t*)big,
+                            (const bf16_t*)small, dW, db, g, M, rpb);
+    return true;
+  }
   if (g.CI == 32) { if (pointwise) MVAE_W16(32, 64, 1); else MVAE_W16(32, 64, 5); }
   else { if (pointwise) MVAE_W16(64, 32, 1); else MVAE_W16(64, 32, 5); }
 #undef MVAE_W16

@@ -125,6 +125,7 @@ int main() {
   test_pw(64, 32, false, false, false, ACT_NONE); test_pw(32, 64, true, false, false, ACT_NONE); test_pw(64, 32, true, false, false, ACT_NONE); test_pw(32, 64, false, false, false, ACT_NONE);
   test_dual(64, 1); test_dual(64, 2); test_dual(32, 1); test_dual(32, 2);
   test_taps(32, 64, 16, 16); test_taps(64, 32, 16, 16); test_taps(32, 64, 12, 20);
+  test_taps(32, 64, 8, 64); test_taps(64, 32, 8, 64); test_taps(32, 64, 6, 128); test_taps(64, 32, 10, 128);   // OW = 32 / 64: k16_wgrad_seg, k16_taps_fr<.., 32>
   test_wgrad_pw(64, 32); test_wgrad_pw(32, 64);
   printf("last hip error: %s\n", hipGetErrorString(hipGetLastError()));
   return 0;
