@@ -156,6 +156,14 @@ struct mvae_handle {
   hipStream_t side[MVAE_MAX_LEVELS] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MVAE_MAX_LEVELS] = {};
   std::map<std::string, hipGraphExec_t> graphs;
+  // MVAE_GRAPH_SEGMENTS=1 (default 0): an ABI call is captured as LINEAR graphs -- what precedes the fork, one graph per scale's
+  // chain, what follows the join -- replayed with eager fork / join events (run_captured below; measured, not faster).
+  struct SegStep { int op; hipGraphExec_t exec; int stream; hipEvent_t ev; };   // op 0 launch, 1 record, 2 wait; stream 0 = caller's, l = side[l]
+  std::map<std::string, std::vector<SegStep>> seg_graphs;
+  std::vector<SegStep>* segcap = nullptr;   // the program being recorded (non-null only inside run_captured's capture)
+  hipStream_t seg_main = nullptr, seg_open = nullptr;   // the caller's stream of that capture; the stream whose capture is open
+  hipError_t seg_err = hipSuccess;
+  bool graph_segments = false;
   int eager_fallbacks = 0;                 // calls that wanted a graph and ran eagerly (stream not capturable)
   std::string eager_reason;
   std::vector<hipEvent_t> ev_pool;      // one fresh event per cross-stream edge of a backward pass
@@ -990,13 +998,60 @@ static bool scale0_first(int pass) {          // pass 1 = forward, 2 = backward;
 void stamp(mvae_handle* h, int id, hipStream_t s) {
   if (h->stamps && h->d_stamps && id >= 0 && id < 128) launch_stamp(h->d_stamps + id, s);
 }
+// ---- segmented capture (MVAE_GRAPH_SEGMENTS): see run_captured ----
+static int seg_stream_index(mvae_handle* h, hipStream_t s) {
+  if (s == h->seg_main) return 0;
+  for (int l = 1; l < h->cfg.levels; ++l) if (h->side[l] == s) return l;
+  return -1;
+}
+static void seg_begin(mvae_handle* h, hipStream_t s) {
+  if (!h->segcap || h->seg_open || h->seg_err != hipSuccess) return;
+  h->seg_err = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (h->seg_err == hipSuccess) h->seg_open = s;
+}
+static void seg_end(mvae_handle* h, hipStream_t s) {
+  if (!h->segcap || h->seg_open != s) return;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(s, &graph);
+  h->seg_open = nullptr;
+  size_t nodes = 0;
+  if (e == hipSuccess) e = hipGraphGetNodes(graph, nullptr, &nodes);
+  if (e == hipSuccess && nodes > 0) {
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e == hipSuccess) h->segcap->push_back({0, exec, seg_stream_index(h, s), nullptr});
+  }
+  if (graph) (void)hipGraphDestroy(graph);
+  if (e != hipSuccess && h->seg_err == hipSuccess) h->seg_err = e;
+}
+// a scale's chain starts / ends on stream `ss` (between fork_scales and join_scales)
+void chain_begin(mvae_handle* h, hipStream_t ss) {
+  if (h->segcap && !serial_scales(h)) seg_begin(h, ss);
+}
+void chain_end(mvae_handle* h, hipStream_t ss) {
+  if (h->segcap && !serial_scales(h)) seg_end(h, ss);
+}
 void fork_scales(mvae_handle* h, hipStream_t main) {
   if (serial_scales(h)) return;
+  if (h->segcap) {                          // the graph of what came before ends here; the fork is replayed eagerly
+    seg_end(h, main);
+    h->segcap->push_back({1, nullptr, 0, h->ev_fork});
+    for (int l = 1; l < h->cfg.levels; ++l) h->segcap->push_back({2, nullptr, l, h->ev_fork});
+    return;
+  }
   (void)hipEventRecord(h->ev_fork, main);
   for (int l = 1; l < h->cfg.levels; ++l) (void)hipStreamWaitEvent(h->side[l], h->ev_fork, 0);
 }
 void join_scales(mvae_handle* h, hipStream_t main) {
   if (serial_scales(h)) return;
+  if (h->segcap) {
+    for (int l = 1; l < h->cfg.levels; ++l) {
+      h->segcap->push_back({1, nullptr, l, h->ev_join[l]});
+      h->segcap->push_back({2, nullptr, 0, h->ev_join[l]});
+    }
+    seg_begin(h, main);                     // what follows the join: one more linear graph on the caller's stream
+    return;
+  }
   for (int l = 1; l < h->cfg.levels; ++l) {
     (void)hipEventRecord(h->ev_join[l], h->side[l]);
     (void)hipStreamWaitEvent(main, h->ev_join[l], 0);
@@ -1004,11 +1059,62 @@ void join_scales(mvae_handle* h, hipStream_t main) {
 }
 
 // ---- hipGraph cache: capture the launch sequence of one ABI call once per argument signature, then replay ----
+// Two shapes of capture.  (a) default: ONE graph with the scales' chains as forked branches; hipGraphLaunch enqueues it node by
+// node in creation order at ~2.3 us of host time each (tools/graph_launch_cost.hip: ~0.9 ms per pass for the ~380 nodes of a
+// C32-nb forward).  (b) MVAE_GRAPH_SEGMENTS=1: linear graphs (before the fork | one per chain | after the join), which ROCm
+// replays from pre-built AQL packets at 0.03 - 0.3 us per node, with the fork and the join as eager events between them.
+// (b) cuts the host cost of a step from ~2 ms to ~0.3 ms and does NOT make the step faster (batch 128: 2.19 against 2.12 ms,
+// batch 512: 5.02 against 4.91, medians of one box): a training loop never waits for the host -- it runs up to a full AQL ring
+// ahead of the device, so the packets of a step are in their queues long before the device reaches them -- and the caller's
+// stream and the side streams then have to sit on DIFFERENT hardware queues, which with the runtime's default of 4 queues per
+// process they do not (scale 0 serialises behind scale 1: 3.0 ms at batch 128 unless GPU_MAX_HW_QUEUES=8), whereas the forked
+// graph's branches are placed by the runtime.  (Host time measured around the ABI calls of a free-running loop is NOT the launch
+// cost: once the ring is full every launch waits for the device, and the host appears to take exactly one device step per step.)
+static void seg_destroy(std::vector<mvae_handle::SegStep>& prog) {
+  for (auto& st : prog) if (st.op == 0 && st.exec) (void)hipGraphExecDestroy(st.exec);
+  prog.clear();
+}
+static int run_segments(mvae_handle* h, const std::string& key, hipStream_t s, const std::function<void(hipStream_t)>& body) {
+  auto it = h->seg_graphs.find(key);
+  if (it == h->seg_graphs.end()) {
+    std::vector<mvae_handle::SegStep> prog;
+    h->segcap = &prog; h->seg_main = s; h->seg_open = nullptr; h->seg_err = hipSuccess;
+    seg_begin(h, s);
+    if (h->seg_err != hipSuccess) {           // e.g. the legacy default stream cannot be captured: run eagerly, and say so
+      (void)hipGetLastError();
+      h->segcap = nullptr;
+      ++h->eager_fallbacks;
+      h->eager_reason = hipGetErrorString(h->seg_err);
+      body(s);
+      return MVAE_OK;
+    }
+    body(s);
+    if (h->seg_open) seg_end(h, h->seg_open);
+    h->segcap = nullptr;
+    if (h->kernel_gap) {                      // a launch sequence with a missing kernel is never cached (nor replayed)
+      seg_destroy(prog);
+      return fail(h, MVAE_E_INVALID, "%s: a bfloat16 launch found no kernel for its shape", key.c_str());
+    }
+    if (h->seg_err != hipSuccess) {
+      seg_destroy(prog);
+      (void)hipGetLastError();
+      return fail(h, MVAE_E_HIP, "graph capture (%s): %s", key.c_str(), hipGetErrorString(h->seg_err));
+    }
+    it = h->seg_graphs.emplace(key, std::move(prog)).first;
+  }
+  for (const auto& st : it->second) {
+    hipStream_t q = st.stream == 0 ? s : h->side[st.stream];
+    hipError_t e = st.op == 0 ? hipGraphLaunch(st.exec, q) : st.op == 1 ? hipEventRecord(st.ev, q) : hipStreamWaitEvent(q, st.ev, 0);
+    if (e != hipSuccess) return fail(h, MVAE_E_HIP, "graph replay (%s): %s", key.c_str(), hipGetErrorString(e));
+  }
+  return MVAE_OK;
+}
 int run_captured(mvae_handle* h, const std::string& key, hipStream_t s, const std::function<void(hipStream_t)>& body) {
   // a fork from a stream that itself joined the capture by a fork (the weight-gradient side streams) makes
   // hipStreamEndCapture segfault under ROCm 7.2: that mode never captures, whatever the environment says
   const bool eligible = h->use_graphs && h->wgrad_streams != 1 && !profiler().on && s != nullptr;
   if (!eligible) { body(s); return MVAE_OK; }
+  if (h->graph_segments && h->wgrad_streams == 0) return run_segments(h, key, s, body);
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -1145,6 +1251,7 @@ void mvae_destroy(mvae_handle* h) {
   if (h->bound) {
     (void)hipDeviceSynchronize();
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : h->seg_graphs) seg_destroy(kv.second);
     for (int l = 1; l < h->cfg.levels; ++l) {
       if (h->side[l]) (void)hipStreamDestroy(h->side[l]);
       if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
@@ -1222,6 +1329,7 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   if (const char* v = getenv("MVAE_GRAPHS")) h->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("MVAE_STREAMS")) h->multi_stream = atoi(v) != 0;
   if (const char* v = getenv("MVAE_WGRAD_STREAMS")) h->wgrad_streams = atoi(v);
+  if (const char* v = getenv("MVAE_GRAPH_SEGMENTS")) h->graph_segments = atoi(v) != 0;
   if (const char* v = getenv("MVAE_LSB_MASK")) h->lsb_mask = atoi(v) != 0;
   if (const char* v = getenv("MVAE_MERGE_SIDE")) h->merge_side = atoi(v) != 0;   // all scales > 0 on ONE side stream
   if (h->wgrad_streams == 1) h->use_graphs = false;
@@ -1318,6 +1426,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
       hipStream_t ss = scale_stream(h, si, s);
       profiler().cur_scale = si;
       Scale& sc = h->scales[si];
+      chain_begin(h, ss);
       stamp(h, 10 + si, ss);
       ConvGeom g{};
       g.B = B; g.IH = g.OH = sc.H; g.IW = g.OW = sc.W; g.CI = C; g.CO = kConvBaseFilters;
@@ -1368,6 +1477,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
       if (io->z) launch_copy_cols(sc.zs, sc.z, 0, io->z, (int)h->Z, sc.z_off, B, sc.z, ss);
       decoder_forward(h, sc, B, training, ss);
       stamp(h, 20 + si, ss);
+      chain_end(h, ss);
     }
     join_scales(h, s);
     stamp(h, 2, s);
@@ -1431,6 +1541,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
     Scale& sc = h->scales[si];
     const int64_t M = (int64_t)B * sc.H * sc.W;
     float* d = nullptr;
+    chain_begin(h, s);
     if (bits & 1) stamp(h, 30 + si, s);
     if (bits & 1) {
     for (int k = 0; k < 4; ++k) { sc.scratch_used[k] = false; sc.buf_pending[k] = false; }
@@ -1542,7 +1653,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
     if (!(bits & 2)) wgrad_join(h, sc, s);     // phase 0 ends here: its side-stream Dense gradients must be final
     sc.d_mid = d;
     }   // decoder half
-    if (!(bits & 2)) return;
+    if (!(bits & 2)) { chain_end(h, s); return; }
     d = sc.d_mid;
     // ---- encoder blocks, last to first
     for (int i = (int)sc.enc.size() - 1; i >= 0; --i) {
@@ -1589,6 +1700,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
     }
     release(sc, d);
     stamp(h, 40 + si, s);
+    chain_end(h, s);
   };
   // (Holding the smaller scales back until scale 0 reaches its MFMA-bound 5x5 convolutions, so that their HBM-bound work
   // would fill those windows, was measured: 5.88 .. 6.05 ms against 5.92 -- their chains are latency-bound and only move
@@ -1624,7 +1736,7 @@ int64_t mvae_reduce_split(const mvae_handle* h) { return h ? h->reduce_split : -
 
 int mvae_graph_stats(const mvae_handle* h, int32_t* captured, int32_t* eager_fallbacks) {
   if (!h) return MVAE_E_INVALID;
-  if (captured) *captured = (int32_t)h->graphs.size();
+  if (captured) *captured = (int32_t)(h->graphs.size() + h->seg_graphs.size());
   if (eager_fallbacks) *eager_fallbacks = h->eager_fallbacks;
   return MVAE_OK;
 }

@@ -235,14 +235,17 @@ def test_graph_replay_and_streams_match_eager(name, B, monkeypatch):
     single-stream path computes (same device-RNG seeds, so identical noise / dropout / epsilon draws).
     Float atomics make even two identical eager runs differ (the notebook's r_loss_factor=1000 amplifies rounding
     noise into Adagrad steps on the biases that feed BatchNorm), so the bound is the measured eager-vs-eager
-    distance: the graph + streams run may lie at most 2x as far from its nearest eager run as the three eager runs lie from each
-    other (a kernel that misbehaves under concurrency moves the weights by a visible share of the distance travelled)."""
+    distance: a graph + streams run may lie at most 4x as far from its nearest eager run as the three eager runs lie from each
+    other (pair distances of one mode scatter by 4x; the noise is ~1 % of the distance travelled, and a kernel that misbehaves
+    under concurrency moves the weights by a visible share of that distance)."""
     from multiscale_variational_autoencoder_amd.initializers import init_params
     x = np.random.default_rng(5).uniform(0, 255, (B,) + tuple(CONFIGS[name]["input_dims"])).astype(np.float32)
     runs = []
-    for graphs, streams in (("0", "0"), ("0", "0"), ("0", "0"), ("1", "1")):
+    # three eager single-stream runs, the forked-graph replay, the segmented replay (MVAE_GRAPH_SEGMENTS=1: linear graphs + events)
+    for graphs, streams, segments in (("0", "0", "0"), ("0", "0", "0"), ("0", "0", "0"), ("1", "1", "0"), ("1", "1", "1")):
         monkeypatch.setenv("MVAE_GRAPHS", graphs)
         monkeypatch.setenv("MVAE_STREAMS", streams)
+        monkeypatch.setenv("MVAE_GRAPH_SEGMENTS", segments)
         eng = _engine(name, B)
         eng.set_params(init_params(eng.param_table, 42))
         xd = eng.to_device(x)
@@ -250,23 +253,28 @@ def test_graph_replay_and_streams_match_eager(name, B, monkeypatch):
         for step in range(4):       # step 0 captures, steps 1.. replay
             eng.train_step(xd, 1e-3, 1000.0, 10.0, 1.0, seed=100 + step)
             mets.append(eng.metrics())
+        if graphs == "1":
+            assert eng.graph_stats() == (3, 0)
         runs.append((eng.get_params(), mets))
-    (pa, ma), (pb, mb), (pe, me), (pc, mc) = runs
+    (pa, ma), (pb, mb), (pe, me) = runs[:3]
     p0 = init_params(eng.param_table, 42)
     flat = lambda d: np.concatenate([np.asarray(d[k], np.float64).ravel() for k in pa])
-    fa, fb, fe, fc = flat(pa), flat(pb), flat(pe), flat(pc)
+    fa, fb, fe = flat(pa), flat(pb), flat(pe)
     travelled = np.linalg.norm(fa - flat(p0))
     # the distance between two runs of the SAME mode scatters by 4x from pair to pair (tools/replay_noise.py: 0.0016 .. 0.0073
     # for eager-eager, graph-graph and eager-graph alike at c32nb B=16): the noise level is the largest of three eager pairs,
-    # the graph run is measured against its nearest eager run
+    # a graph run is measured against its nearest eager run
     noise = max(np.linalg.norm(fa - fb), np.linalg.norm(fa - fe), np.linalg.norm(fb - fe))
-    dist = min(np.linalg.norm(fc - fa), np.linalg.norm(fc - fb), np.linalg.norm(fc - fe))
-    assert np.isfinite(fc).all()
-    assert dist <= 2.0 * max(noise, 1e-3 * travelled), (dist, noise, travelled)
-    for m1, m2, m4, m3 in zip(ma, mb, me, mc):
-        for k in m1:
-            floor = max(abs(m1[k] - m2[k]), abs(m1[k] - m4[k]), abs(m2[k] - m4[k]), 1e-4 * abs(m1[k]), 1e-9)
-            assert min(abs(m3[k] - m1[k]), abs(m3[k] - m2[k]), abs(m3[k] - m4[k])) <= 5.0 * floor, (k, m1[k], m2[k], m4[k], m3[k])
+    for pc, mc in runs[3:]:
+        fc = flat(pc)
+        dist = min(np.linalg.norm(fc - fa), np.linalg.norm(fc - fb), np.linalg.norm(fc - fe))
+        assert np.isfinite(fc).all()
+        assert dist <= 4.0 * max(noise, 1e-3 * travelled), (dist, noise, travelled)
+        assert dist <= 0.1 * travelled, (dist, travelled)
+        for m1, m2, m4, m3 in zip(ma, mb, me, mc):
+            for k in m1:
+                floor = max(abs(m1[k] - m2[k]), abs(m1[k] - m4[k]), abs(m2[k] - m4[k]), 1e-4 * abs(m1[k]), 1e-9)
+                assert min(abs(m3[k] - m1[k]), abs(m3[k] - m2[k]), abs(m3[k] - m4[k])) <= 8.0 * floor, (k, m1[k], m2[k], m4[k], m3[k])
 
 
 def test_c256nb_full_size_parity_and_training():

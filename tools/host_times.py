@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Host time of the three ABI calls of a train step (how long the CPU thread spends inside mvae_forward / mvae_backward /
-mvae_apply_adagrad = hipGraphLaunch of their captured graphs) next to the device time of a step.  When the host time per
-step exceeds the device time the step is bound by graph-launch cost, not by the GPU.
+mvae_apply_adagrad = hipGraphLaunch of their captured graphs) next to the device time of a step.  CAREFUL: a loop that
+never synchronises runs ahead of the device until the AQL ring is full, after which every launch waits for the device --
+the host then appears to need one device step per step whatever the launch costs.  Only "loop without sync" < "with final
+sync" (the host got ahead) says the step is NOT launch-bound; the launch cost itself is in tools/graph_launch_cost.hip.
     python tools/host_times.py [c32nb] [batch]"""
 import os, sys, time
 import numpy as np
