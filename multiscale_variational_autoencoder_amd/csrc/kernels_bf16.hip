@@ -869,7 +869,7 @@ template <int KC, int NC, int NTHR, bool CHAIN = false>
 __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ in, const float* __restrict__ W,
                                                    const float* __restrict__ bias, bf16_t* __restrict__ out, ConvGeom g,
                                                    unsigned in_bytes, int tiles_per_wave, const float* __restrict__ W2,
-                                                   const float* __restrict__ bias2, bf16_t* __restrict__ out2) {
+                                                   const float* __restrict__ bias2, bf16_t* __restrict__ out2, int dbg) {
   constexpr int NT = NC / 32, KK = KC / 16;
   static_assert(!CHAIN || NC == 64, "chained conv0: 64 output channels");
   __shared__ __attribute__((aligned(16))) char sW2[CHAIN ? 8 * 64 * 16 + 64 * 4 : 16];
@@ -889,10 +889,14 @@ __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ i
   }
   constexpr int CPP = KC / 8, LX = KC / 16;
   __shared__ __attribute__((aligned(16))) char sW[25 * NC * KC * 2];
-  __shared__ __attribute__((aligned(16))) char sA[(NTHR / 64) * 32 * KC * 2];
+  // per wave: the gathered 32 x KC tile of an offset; in the epilogue the same bytes stage one phase's (NC = 64: 32 pixels x
+  // 128 B) or one output row's (NC = 32: 64 pixels x 64 B) packed results, row pitch + 16 B, for the line-contiguous stores
+  constexpr int OROW = NC == 64 ? 128 : 64, OSLOTS = NC == 64 ? 32 : 64, OPITCH = OROW + 16;
+  constexpr int ABYTES = (32 * KC * 2 > OSLOTS * OPITCH) ? 32 * KC * 2 : OSLOTS * OPITCH;
+  __shared__ __attribute__((aligned(16))) char sA[(NTHR / 64) * ABYTES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  char* myA = sA + wave * (32 * KC * 2);
+  char* myA = sA + wave * ABYTES;
   const int CH = g.OH, CW = g.OW;
   const unsigned Mc = (unsigned)(g.B * CH * CW);
   // ---- all 25 weight slices -> LDS, bf16, T layout [tap][n][k] (W[tap][n = ci][k = co]), chunks XOR-swizzled as k16_taps
@@ -911,9 +915,20 @@ __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ i
     if (pow2) { cx = (int)(p & (unsigned)(CW - 1)); cy = (int)((p >> lgw) & (unsigned)(CH - 1)); b = (int)(p >> (lgw + lgh)); }
     else { cx = (int)(p % (unsigned)CW); const unsigned q = p / (unsigned)CW; cy = (int)(q % (unsigned)CH); b = (int)(q / (unsigned)CH); }
   };
-  const unsigned wtile0 = ((unsigned)blockIdx.x * (unsigned)(NTHR / 64) + wave) * (unsigned)tiles_per_wave;
+  // tile order.  CW % 32 == 0: a tile is 32 positions of ONE row; the block walks down a 32-wide column strip with its waves on
+  // vertically adjacent rows (tile t of the block's run -> row cy = t % CH of strip (t / CH) % strips), so the rows a wave
+  // gathers for dy = -1, 0, 1 are the rows its neighbours gather too and come from the CU's L1 instead of nine times from L2.
+  const bool strips_on = (CW & 31) == 0 && !(dbg & 8);       // (dbg bit 3: MVAE_TD_DBG=8, plain row-major tile order)
+  const unsigned nstrip = (unsigned)(CW >> 5);
+  auto tile_p0 = [&](int ti) -> unsigned {
+    if (!strips_on) return (((unsigned)blockIdx.x * (unsigned)(NTHR / 64) + wave) * (unsigned)tiles_per_wave + (unsigned)ti) * 32u;
+    const unsigned t = (unsigned)blockIdx.x * (unsigned)(NTHR / 64) * (unsigned)tiles_per_wave + (unsigned)ti * (unsigned)(NTHR / 64) + wave;
+    const unsigned cy = t % (unsigned)CH, q = t / (unsigned)CH;
+    const unsigned sx = q % nstrip, b = q / nstrip;
+    return b >= (unsigned)g.B ? Mc : ((b * (unsigned)CH + cy) * (unsigned)CW + sx * 32u);
+  };
   for (int ti = 0; ti < tiles_per_wave; ++ti) {
-    const unsigned p0 = (wtile0 + ti) * 32u;
+    const unsigned p0 = tile_p0(ti);
     if (p0 >= Mc) break;                                       // wave-uniform
     unsigned base[LX], inv[LX];
 #pragma unroll
@@ -977,11 +992,30 @@ __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ i
 #pragma unroll
       for (int j = 0; j < LX; ++j) xc[j] = xn[j];
     }
-    // ---- epilogue per phase: bias, pack, 16-byte stores (as k16_taps)
+    // ---- epilogue per phase: bias, pack; stores.  Per-lane stores (lane (r, h) -> 16 bytes of output pixel 2 (cx0 + r) + px) put
+    // 64 pieces of 16 / 32 bytes, 256 bytes apart, into every store instruction: 1024 partial-line requests per tile, and the
+    // memory pipeline's request rate -- not its bandwidth -- set the kernel's time (skipping the stores: -65 .. -140 us of ~300 at
+    // 256 x 256).  With the tile in one image row (strips_on) the packed results go through the wave's LDS tile and leave as
+    // whole 128-byte lines: NC = 64: per phase 32 pixels x 128 B (8 lanes per pixel); NC = 32: per output row the 64 pixels
+    // 2 cx0 .. 2 cx0 + 63 x 64 B = 4 KB contiguous.
     const unsigned p = p0 + r;
     int cx, cy, b;
     split(p < Mc ? p : 0u, cx, cy, b);
     const int64_t opix00 = (int64_t)(b * g.IH + cy * 2) * g.IW + cx * 2;
+    int cx0, cy0, b0;
+    split(p0, cx0, cy0, b0);
+    auto stage_put = [&](int slot, int chunk, const u32x4& v) { *reinterpret_cast<u32x4*>(myA + slot * OPITCH + chunk * 16) = v; };
+    auto flush64 = [&](bf16_t* dst, int px, int py) {            // NC = 64: staged 32 pixels x 128 B of phase (py, px)
+      WAVE_LDS_SYNC16();
+      char* row = reinterpret_cast<char*>(dst) + ((int64_t)(b0 * g.IH + cy0 * 2 + py) * g.IW + cx0 * 2 + px) * 128;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = j * 64 + lane, slot = q >> 3, c = q & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(myA + slot * OPITCH + c * 16);
+        *reinterpret_cast<u32x4*>(row + (int64_t)slot * 256 + c * 16) = v;
+      }
+      WAVE_LDS_SYNC16();
+    };
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
       const int64_t opix = opix00 + (ph >> 1) * g.IW + (ph & 1);
@@ -1004,7 +1038,26 @@ __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ i
           auto s1 = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
           const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
           if constexpr (CHAIN) och[2 * nt + pp] = o;
-          if (p < Mc) *reinterpret_cast<u32x4*>(out + opix * NC + nt * 32 + 16 * pp + 8 * h) = o;
+          if (strips_on) {
+            if constexpr (NC == 64) stage_put(r, nt * 4 + pp * 2 + h, o);
+            else stage_put(2 * r + (ph & 1), pp * 2 + h, o);
+          } else if (p < Mc) {
+            *reinterpret_cast<u32x4*>(out + opix * NC + nt * 32 + 16 * pp + 8 * h) = o;
+          }
+        }
+      }
+      if (strips_on) {
+        if constexpr (NC == 64) {
+          flush64(out, ph & 1, ph >> 1);
+        } else if (ph & 1) {                                     // NC = 32: both px phases of output row py are staged
+          WAVE_LDS_SYNC16();
+          char* row = reinterpret_cast<char*>(out) + ((int64_t)(b0 * g.IH + cy0 * 2 + (ph >> 1)) * g.IW + cx0 * 2) * 64;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int q = j * 64 + lane, slot = q >> 2, c = q & 3;
+            *reinterpret_cast<u32x4*>(row + (int64_t)q * 16) = *reinterpret_cast<const u32x4*>(myA + slot * OPITCH + c * 16);
+          }
+          WAVE_LDS_SYNC16();
         }
       }
       if constexpr (CHAIN) {
@@ -1032,9 +1085,12 @@ __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ i
             uint2 a = pk[2 * pp], bb = pk[2 * pp + 1];
             auto s0 = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
             auto s1 = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
-            if (p < Mc) *reinterpret_cast<u32x4*>(out2 + opix * 64 + nt * 32 + 16 * pp + 8 * h) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            const u32x4 o2 = {s0[0], s1[0], s0[1], s1[1]};
+            if (strips_on) stage_put(r, nt * 4 + pp * 2 + h, o2);
+            else if (p < Mc) *reinterpret_cast<u32x4*>(out2 + opix * 64 + nt * 32 + 16 * pp + 8 * h) = o2;
           }
         }
+        if (strips_on) flush64(out2, ph & 1, ph >> 1);
       }
     }
   }
@@ -1881,16 +1937,19 @@ bool launch16_taps(bool transposed, const void* in, const float* w, const float*
     if (wv > tiles_m) wv = tiles_m;
     const int tpw_m = (int)((tiles_m + wv - 1) / wv);
     const unsigned gxm = (unsigned)(((tiles_m + tpw_m - 1) / tpw_m + 7) / 8);
-    if (KC == 32 && NC == 64 && w2 && out2 && chain_m) {
+    // MVAE_TM_FLAGS16 (diagnostic bit mask): 8 = plain row-major tile order and per-lane 16-byte stores (the round-4 first form)
+    static const int dbg = [] { const char* e = getenv("MVAE_TM_FLAGS16"); return e ? atoi(e) : 0; }();
+    const bool chain_here = KC == 32 && NC == 64 && w2 && out2 && chain_m;
+    if (chain_here) {
       hipLaunchKernelGGL((k16_taps_tm<32, 64, 512, true>), dim3(gxm), dim3(512), 0, s, (const bf16_t*)in, w, bias, (bf16_t*)out, g,
-                         in_bytes, tpw_m, w2, bias2, (bf16_t*)out2);
+                         in_bytes, tpw_m, w2, bias2, (bf16_t*)out2, dbg);
       if (chained) *chained = true;
     } else if (KC == 32 && NC == 64) {
       hipLaunchKernelGGL((k16_taps_tm<32, 64, 512, false>), dim3(gxm), dim3(512), 0, s, (const bf16_t*)in, w, bias, (bf16_t*)out, g,
-                         in_bytes, tpw_m, nullptr, nullptr, nullptr);
+                         in_bytes, tpw_m, nullptr, nullptr, nullptr, dbg);
     } else {
       hipLaunchKernelGGL((k16_taps_tm<64, 32, 512, false>), dim3(gxm), dim3(512), 0, s, (const bf16_t*)in, w, bias, (bf16_t*)out, g,
-                         in_bytes, tpw_m, nullptr, nullptr, nullptr);
+                         in_bytes, tpw_m, nullptr, nullptr, nullptr, dbg);
     }
     return true;
   }

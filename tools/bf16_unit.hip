@@ -2,6 +2,7 @@
 // time.  Build (on the GPU box or here): hipcc --offload-arch=gfx950 -O2 tools/bf16_unit.hip csrc/kernels_bf16.o
 // csrc/kernels_generic.o csrc/dispatch.o ... -o bf16_unit   (see tools/run_bf16_unit.sh)
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -119,8 +120,43 @@ static void test_wgrad_pw(int CI, int CO) {
   GradSlots sl; bool ok = launch16_wgrad(dB, dS, gW, gb, g, sl, nullptr); hipDeviceSynchronize();
   printf("wgrad 1x1 %d,%d: launched=%d dW rel=%.3e db rel=%.3e\n", CI, CO, ok, relerr(rw, f2d(host(gW, CI * CO))), relerr(rbias, f2d(host(gb, CO))));
 }
-int main() {
+// timing only (no reference): the 5 x 5 stride-2 family at the sizes of a C256-nb step.   bf16_unit.bin time [B]
+static uint16_t* dev_pattern(size_t n) {
+  std::vector<uint16_t> pat(1 << 20); for (auto& v : pat) v = f2b(rnd());
+  uint16_t* p; hipMalloc(&p, n * 2);
+  for (size_t o = 0; o < n; o += pat.size()) hipMemcpy(p + o, pat.data(), std::min(pat.size(), n - o) * 2, hipMemcpyHostToDevice);
+  return p;
+}
+static void time_taps(int CI, int CO, int B, int IH, int IW) {
+  ConvGeom g{}; g.B = B; g.IH = IH; g.IW = IW; g.CI = CI; g.CO = CO; g.KH = g.KW = 5; g.SH = g.SW = 2; g.OH = IH / 2; g.OW = IW / 2; g.PT = g.PL = 1;
+  const size_t nb = (size_t)B * IH * IW * CI, ns = (size_t)B * g.OH * g.OW * CO;
+  uint16_t *big = dev_pattern(nb), *small = dev_pattern(ns), *oS, *oB; hipMalloc(&oS, ns * 2); hipMalloc(&oB, nb * 2);
+  std::vector<float> W(25 * CI * CO), bias(64, 0.f); for (auto& v : W) v = rnd() * 0.1f;
+  auto dWt = dev(W); auto db = dev(bias); float *gW, *gb; hipMalloc(&gW, W.size() * 4); hipMalloc(&gb, 64 * 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const double flops = 2.0 * B * g.OH * g.OW * 25.0 * CI * CO;
+  for (int which = 0; which < 3; ++which) {
+    const int reps = 8; float ms = 0;
+    for (int r = -2; r < reps; ++r) {
+      if (r == 0) hipEventRecord(e0, nullptr);
+      if (which == 0) launch16_taps(false, big, dWt, db, oS, g, nullptr);
+      else if (which == 1) launch16_taps(true, small, dWt, db, oB, g, nullptr);
+      else { GradSlots sl; launch16_wgrad(big, small, gW, gb, g, sl, nullptr); }
+    }
+    hipEventRecord(e1, nullptr); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    const char* nm[] = {"F (conv)", "T (convT)", "wgrad"};
+    printf("time %-9s %d<->%d B=%d %dx%d: %8.1f us  %6.1f TFLOP/s\n", nm[which], CI, CO, B, IH, IW, ms * 1000 / reps, flops / (ms / reps * 1e-3) / 1e12);
+  }
+  hipFree(big); hipFree(small); hipFree(oS); hipFree(oB); hipFree(gW); hipFree(gb);
+}
+int main(int argc, char** argv) {
   srand(1);
+  if (argc > 1 && !strcmp(argv[1], "time")) {
+    const int B = argc > 2 ? atoi(argv[2]) : 64;
+    for (int sz = 256; sz >= 32; sz /= 2) { time_taps(32, 64, B, sz, sz); time_taps(64, 32, B, sz, sz); }
+    printf("last hip error: %s\n", hipGetErrorString(hipGetLastError()));
+    return 0;
+  }
   test_pw(64, 64, false, false, false, ACT_RELU); test_pw(64, 64, false, true, true, ACT_NONE); test_pw(32, 32, false, true, true, ACT_NONE);
   test_pw(64, 32, false, false, false, ACT_NONE); test_pw(32, 64, true, false, false, ACT_NONE); test_pw(64, 32, true, false, false, ACT_NONE); test_pw(32, 64, false, false, false, ACT_NONE);
   test_dual(64, 1); test_dual(64, 2); test_dual(32, 1); test_dual(32, 2);
