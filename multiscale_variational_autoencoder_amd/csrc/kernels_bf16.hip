@@ -865,7 +865,7 @@ __device__ __forceinline__ constexpr int o_ny(int oi) { return o_dy(oi) == 1 ? 1
 __device__ __forceinline__ constexpr int o_nx(int oi) { return o_dx(oi) == 1 ? 1 : 2; }
 }  // namespace tm16
 
-template <int KC, int NC, int NTHR, bool CHAIN = false>
+template <int KC, int NC, int NTHR, bool CHAIN = false, bool ROWS = false>
 __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ in, const float* __restrict__ W,
                                                    const float* __restrict__ bias, bf16_t* __restrict__ out, ConvGeom g,
                                                    unsigned in_bytes, int tiles_per_wave, const float* __restrict__ W2,
@@ -892,7 +892,13 @@ __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ i
   // per wave: the gathered 32 x KC tile of an offset; in the epilogue the same bytes stage one phase's (NC = 64: 32 pixels x
   // 128 B) or one output row's (NC = 32: 64 pixels x 64 B) packed results, row pitch + 16 B, for the line-contiguous stores
   constexpr int OROW = NC == 64 ? 128 : 64, OSLOTS = NC == 64 ? 32 : 64, OPITCH = OROW + 16;
-  constexpr int ABYTES = (32 * KC * 2 > OSLOTS * OPITCH) ? 32 * KC * 2 : OSLOTS * OPITCH;
+  // ROWS (launched when CW % 32 == 0, KC = 32): the tile's 3 x 34 input pixels (rows cy - 1 .. cy + 1, columns cx0 - 1 .. cx0 + 32)
+  // are requested ONE TILE AHEAD (7 coalesced 16-byte loads per lane), written to the wave's LDS tile once, and the nine offsets
+  // read their fragments from it at block dy + 1, row r + dx + 1: one wait and 6.5 KB of LDS writes per tile instead of nine
+  // gathers of 2 KB with a wait each (the gathers' latency, one offset of prefetch deep, was what the waves waited for).
+  constexpr int RPX = 34, RCH = RPX * (KC / 8), RTOT = 3 * RCH, NLR = (RTOT + 63) / 64;
+  constexpr int GBYTES = ROWS ? 3 * RPX * KC * 2 : 32 * KC * 2;
+  constexpr int ABYTES = (GBYTES > OSLOTS * OPITCH) ? GBYTES : OSLOTS * OPITCH;
   __shared__ __attribute__((aligned(16))) char sA[(NTHR / 64) * ABYTES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -921,12 +927,27 @@ __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ i
   const bool strips_on = (CW & 31) == 0 && !(dbg & 8);       // (dbg bit 3: MVAE_TD_DBG=8, plain row-major tile order)
   const unsigned nstrip = (unsigned)(CW >> 5);
   auto tile_p0 = [&](int ti) -> unsigned {
+    if (ti >= tiles_per_wave) return Mc;
     if (!strips_on) return (((unsigned)blockIdx.x * (unsigned)(NTHR / 64) + wave) * (unsigned)tiles_per_wave + (unsigned)ti) * 32u;
     const unsigned t = (unsigned)blockIdx.x * (unsigned)(NTHR / 64) * (unsigned)tiles_per_wave + (unsigned)ti * (unsigned)(NTHR / 64) + wave;
     const unsigned cy = t % (unsigned)CH, q = t / (unsigned)CH;
     const unsigned sx = q % nstrip, b = q / nstrip;
     return b >= (unsigned)g.B ? Mc : ((b * (unsigned)CH + cy) * (unsigned)CW + sx * 32u);
   };
+  u32x4 xr[ROWS ? NLR : 1];
+  auto request_rows = [&](unsigned q0) {                         // the 3 x 34 pixels around the tile that starts at position q0
+    const bool valid = q0 < Mc;
+    int cx0, cy0, b0;
+    split(valid ? q0 : 0u, cx0, cy0, b0);
+#pragma unroll
+    for (int u = 0; u < (ROWS ? NLR : 1); ++u) {
+      const int i = u * 64 + lane, rowi = i / RCH, rem = i - rowi * RCH;
+      const int y = cy0 + rowi - 1, x = cx0 - 1 + rem / CPP;
+      const bool ok = valid && i < RTOT && (unsigned)y < (unsigned)CH && (unsigned)x < (unsigned)CW;
+      xr[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (unsigned)(((b0 * CH + y) * CW + x) * KC + (rem % CPP) * 8) * 2u : 0x80000000u, 0, 0);
+    }
+  };
+  if constexpr (ROWS) request_rows(tile_p0(0));
   for (int ti = 0; ti < tiles_per_wave; ++ti) {
     const unsigned p0 = tile_p0(ti);
     if (p0 >= Mc) break;                                       // wave-uniform
@@ -958,21 +979,37 @@ __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ i
       for (int j = 0; j < LX; ++j)
         dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (inv[j] & sel) ? 0x80000000u : base[j] + delta, 0, 0);
     };
-    fetch(0, xc);
+    if constexpr (ROWS) {
+      WAVE_LDS_SYNC16();                                         // the previous tile's staged results have left
+#pragma unroll
+      for (int u = 0; u < NLR; ++u) {
+        const int i = u * 64 + lane, rowi = i / RCH, rem = i - rowi * RCH;
+        if (i < RTOT) *reinterpret_cast<u32x4*>(myA + rowi * (RPX * KC * 2) + tile_off<KC>(rem / CPP, rem % CPP)) = xr[u];
+      }
+      request_rows(tile_p0(ti + 1));                             // the next tile's rows: in flight under this tile's 100 MFMAs
+      WAVE_LDS_SYNC16();
+    } else {
+      fetch(0, xc);
+    }
 #pragma unroll
     for (int oi = 0; oi < 9; ++oi) {
-      if (oi + 1 < 9) fetch(oi + 1, xn);                        // next offset's rows in flight under this offset's taps
-      WAVE_LDS_SYNC16();                                         // the previous offset's fragment reads are done
-#pragma unroll
-      for (int j = 0; j < LX; ++j) {
-        const int c = j * 64 + lane;
-        *reinterpret_cast<u32x4*>(myA + tile_off<KC>(c / CPP, c % CPP)) = xc[j];
-      }
-      WAVE_LDS_SYNC16();
       bf16x8 xb[KK];
+      if constexpr (ROWS) {
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) xb[kk] = frag_rows<KC>(myA, r, h, kk);
-      constexpr int dummy = 0; (void)dummy;
+        for (int kk = 0; kk < KK; ++kk)       // (image row dy + 1 is its own swizzled block: six distinct lane addresses in all)
+          xb[kk] = frag_rows<KC>(myA + (tm16::o_dy(oi) + 1) * (RPX * KC * 2), r + tm16::o_dx(oi) + 1, h, kk);
+      } else {
+        if (oi + 1 < 9) fetch(oi + 1, xn);                      // next offset's rows in flight under this offset's taps
+        WAVE_LDS_SYNC16();                                       // the previous offset's fragment reads are done
+#pragma unroll
+        for (int j = 0; j < LX; ++j) {
+          const int c = j * 64 + lane;
+          *reinterpret_cast<u32x4*>(myA + tile_off<KC>(c / CPP, c % CPP)) = xc[j];
+        }
+        WAVE_LDS_SYNC16();
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) xb[kk] = frag_rows<KC>(myA, r, h, kk);
+      }
 #pragma unroll
       for (int jy = 0; jy < tm16::o_ny(oi); ++jy)
 #pragma unroll
@@ -989,9 +1026,12 @@ __global__ void __launch_bounds__(NTHR) k16_taps_tm(const bf16_t* __restrict__ i
               acc[py * 2 + px][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[kk], acc[py * 2 + px][nt], 0, 0, 0);
             }
         }
+      if constexpr (!ROWS) {
 #pragma unroll
-      for (int j = 0; j < LX; ++j) xc[j] = xn[j];
+        for (int j = 0; j < LX; ++j) xc[j] = xn[j];
+      }
     }
+    if constexpr (ROWS) WAVE_LDS_SYNC16();                       // the fragment reads are done: the tile's bytes now stage the results
     // ---- epilogue per phase: bias, pack; stores.  Per-lane stores (lane (r, h) -> 16 bytes of output pixel 2 (cx0 + r) + px) put
     // 64 pieces of 16 / 32 bytes, 256 bytes apart, into every store instruction: 1024 partial-line requests per tile, and the
     // memory pipeline's request rate -- not its bandwidth -- set the kernel's time (skipping the stores: -65 .. -140 us of ~300 at
@@ -1940,17 +1980,17 @@ bool launch16_taps(bool transposed, const void* in, const float* w, const float*
     // MVAE_TM_FLAGS16 (diagnostic bit mask): 8 = plain row-major tile order and per-lane 16-byte stores (the round-4 first form)
     static const int dbg = [] { const char* e = getenv("MVAE_TM_FLAGS16"); return e ? atoi(e) : 0; }();
     const bool chain_here = KC == 32 && NC == 64 && w2 && out2 && chain_m;
-    if (chain_here) {
-      hipLaunchKernelGGL((k16_taps_tm<32, 64, 512, true>), dim3(gxm), dim3(512), 0, s, (const bf16_t*)in, w, bias, (bf16_t*)out, g,
-                         in_bytes, tpw_m, w2, bias2, (bf16_t*)out2, dbg);
-      if (chained) *chained = true;
-    } else if (KC == 32 && NC == 64) {
-      hipLaunchKernelGGL((k16_taps_tm<32, 64, 512, false>), dim3(gxm), dim3(512), 0, s, (const bf16_t*)in, w, bias, (bf16_t*)out, g,
-                         in_bytes, tpw_m, nullptr, nullptr, nullptr, dbg);
-    } else {
-      hipLaunchKernelGGL((k16_taps_tm<64, 32, 512, false>), dim3(gxm), dim3(512), 0, s, (const bf16_t*)in, w, bias, (bf16_t*)out, g,
-                         in_bytes, tpw_m, nullptr, nullptr, nullptr, dbg);
-    }
+    // KC = 32 and whole 32-position tiles per row: the tile's 3 x 34 input pixels staged once, one tile ahead (ROWS)
+    static const bool rows_t = [] { const char* e = getenv("MVAE_TM_ROWS16"); return e ? atoi(e) != 0 : true; }();
+    const bool rows_here = rows_t && KC == 32 && g.OW % 32 == 0 && !(dbg & 8);
+#define MVAE_TM(A, B_, CH_, RW_)                                                                                       \
+  hipLaunchKernelGGL((k16_taps_tm<A, B_, 512, CH_, RW_>), dim3(gxm), dim3(512), 0, s, (const bf16_t*)in, w, bias, (bf16_t*)out, g, \
+                     in_bytes, tpw_m, CH_ ? w2 : nullptr, CH_ ? bias2 : nullptr, CH_ ? (bf16_t*)out2 : nullptr, dbg)
+    if (chain_here) { if (rows_here) MVAE_TM(32, 64, true, true); else MVAE_TM(32, 64, true, false); }
+    else if (KC == 32 && NC == 64) { if (rows_here) MVAE_TM(32, 64, false, true); else MVAE_TM(32, 64, false, false); }
+    else MVAE_TM(64, 32, false, false);
+#undef MVAE_TM
+    if (chained) *chained = chain_here;
     return true;
   }
   // F-form with the input rows of a kernel row staged in LDS (k16_taps_fr): 5 x 5, stride 2, output width 4 / 8 / 16 / 32k
