@@ -116,7 +116,7 @@ void launch_colsum(const float* x, float* out, int64_t M, int C, hipStream_t s);
 // vectorised column statistics into slot copies (kernels_opt.hip); mode 0: sum, mode 1: squared deviations from
 // mean = inv_m * (sum of the msl slot copies of msum).  false = shape not covered.
 bool launch_colstat_opt(int mode, const float* x, const float* msum, int msl, float inv_m, float* out, int nslots,
-                        int64_t slot_stride, int64_t M, int C, hipStream_t s, bool bf = false);
+                        int64_t slot_stride, int64_t M, int C, hipStream_t s, bool bf = false, float* out2 = nullptr);
 constexpr int kStatSlots = 16;
 // out[c] += sum_m (x[m,c]-mean[c])^2
 void launch_colsqdev(const float* x, const float* mean, float* out, int64_t M, int C, hipStream_t s);
@@ -151,7 +151,7 @@ void launch_bn1d_bwd(const float* dy, const float* xhat, const float* invstd, co
 void launch_bn2d_finalize(const float* sum, const float* sqdev, const float* gamma, const float* beta,
                           const float* mov_mean, const float* mov_var, float* mean, float* invstd, float* scale,
                           float* shift, float* stat_mean, float* stat_var, int64_t M, int C, float eps, int training, int nslots,
-                          hipStream_t s);
+                          hipStream_t s, const float* pivot = nullptr);
 void launch_scale_vec(float* v, float a, int n, hipStream_t s);
 // dx = scale_c * (d - sum_d/M - xhat * sum_dx/M)   in place on d ; dgamma += sum_dx ; dbeta += sum_d
 void launch_bn2d_bwd_apply(float* d, const float* x, const float* mean, const float* invstd, const float* gamma,

@@ -1045,13 +1045,14 @@ void launch_bn1d_bwd(const float* dy, const float* xhat, const float* invstd, co
 __global__ void k_bn2d_finalize(const float* sum, const float* sqdev, const float* gamma, const float* beta,
                                 const float* mov_mean, const float* mov_var, float* mean, float* invstd, float* scale,
                                 float* shift, float* stat_mean, float* stat_var, float inv_m, int C, float eps,
-                                int training, int phase, int nslots) {
+                                int training, int phase, int nslots, const float* pivot) {
+  // pivot != nullptr (one-pass statistics, k_colstat4<2>): sum = S1 = sum (x - pivot), sqdev = S2 = sum (x - pivot)^2
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float mu = 0.f;
+  float mu = 0.f, s1 = 0.f;
   if (training) {
-    for (int k = 0; k < nslots; ++k) mu += sum[k * C + c];
-    mu *= inv_m;
+    for (int k = 0; k < nslots; ++k) s1 += sum[k * C + c];
+    mu = s1 * inv_m + (pivot ? pivot[c] : 0.f);
   } else {
     mu = mov_mean[c];
   }
@@ -1060,6 +1061,7 @@ __global__ void k_bn2d_finalize(const float* sum, const float* sqdev, const floa
   float var = 0.f;
   if (training) {
     for (int k = 0; k < nslots; ++k) var += sqdev[k * C + c];
+    if (pivot) var = fmaxf(var - s1 * (s1 * inv_m), 0.f);
     var *= inv_m;
   } else {
     var = mov_var[c];
@@ -1075,15 +1077,15 @@ void launch_bn2d_mean(const float* sum, const float* mov_mean, float* mean, int6
                       hipStream_t s) {
   ProfScope ps("bn2d_small", (double)(0.0), 0.0, s);
   hipLaunchKernelGGL(k_bn2d_finalize, dim3((C + 63) / 64), dim3(64), 0, s, sum, nullptr, nullptr, nullptr, mov_mean,
-                     nullptr, mean, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f / (float)M, C, 0.f, training, 0, 1);
+                     nullptr, mean, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f / (float)M, C, 0.f, training, 0, 1, nullptr);
 }
 void launch_bn2d_finalize(const float* sum, const float* sqdev, const float* gamma, const float* beta,
                           const float* mov_mean, const float* mov_var, float* mean, float* invstd, float* scale,
                           float* shift, float* stat_mean, float* stat_var, int64_t M, int C, float eps, int training,
-                          int nslots, hipStream_t s) {
+                          int nslots, hipStream_t s, const float* pivot) {
   ProfScope ps("bn2d_small", (double)(0.0), 0.0, s);
   hipLaunchKernelGGL(k_bn2d_finalize, dim3((C + 63) / 64), dim3(64), 0, s, sum, sqdev, gamma, beta, mov_mean, mov_var,
-                     mean, invstd, scale, shift, stat_mean, stat_var, 1.0f / (float)M, C, eps, training, 1, nslots);
+                     mean, invstd, scale, shift, stat_mean, stat_var, 1.0f / (float)M, C, eps, training, 1, nslots, pivot);
 }
 
 __global__ void k_bn2d_bwd_apply(float* __restrict__ d, const float* __restrict__ x, const float* __restrict__ mean,

@@ -352,13 +352,17 @@ bool launch_dw_wgrad_opt(const float* in, const float* dy, float* dW, float* db,
 // ------------------------------------------------------------------------------------------------
 // Column statistics of a [M, C] tensor, 16 bytes per lane, 8 independent loads in flight per thread.
 //   MODE 0: out[c] += sum_m x[m,c]            MODE 1: out[c] += sum_m (x[m,c] - mean[c])^2,
-// mean[c] = inv_m * sum over the `msl` slot copies of a MODE 0 result.  The block's result leaves as one atomic set into
+// mean[c] = inv_m * sum over the `msl` slot copies of a MODE 0 result.
+//   MODE 2 (round 4): both moments in ONE pass about a pivot: d = x[m,c] - x[0,c]; out[c] += sum d, out2[c] += sum d^2.  The
+// finalize kernel turns them into mean = x[0,c] + S1 / M and M var = S2 - S1^2 / M: the pivot is a sample of the column, so
+// (mean - pivot)^2 is of the order of the variance and the subtraction loses a few bits at most (a pivot of 0, i.e.
+// E[x^2] - E[x]^2, would lose log2(mean^2 / var) of them).  Saves a full read pass of the decoder's last activation.  The block's result leaves as one atomic set into
 // slot (block % nslots) (kernels.h: GradSlots -- a few hundred blocks adding into ONE 128-byte line serialise).
 // ------------------------------------------------------------------------------------------------
 template <int MODE, typename T>
 __global__ void __launch_bounds__(256) k_colstat4(const V4<T> x, const float* __restrict__ msum, int msl,
                                                   float inv_m, float* __restrict__ out, int nslots, int64_t slot_stride,
-                                                  int64_t M, int C4, int64_t rpb) {
+                                                  int64_t M, int C4, int64_t rpb, float* __restrict__ out2) {
   __shared__ f32x4 red[4][64];
   const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, nr = 256 / C4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -367,6 +371,8 @@ __global__ void __launch_bounds__(256) k_colstat4(const V4<T> x, const float* __
     for (int k = 0; k < msl; ++k) mean += reinterpret_cast<const f32x4*>(msum + (int64_t)k * C4 * 4)[c4];
     mean *= inv_m;
   }
+  if (MODE == 2) mean = V4<T>::cv(x.ld(c4));              // the pivot: row 0 of the column
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
   const int64_t m0 = (int64_t)blockIdx.x * rpb;
   int64_t m1 = m0 + rpb;
   if (m1 > M) m1 = M;
@@ -386,9 +392,13 @@ __global__ void __launch_bounds__(256) k_colstat4(const V4<T> x, const float* __
       const f32x4 v = V4<T>::cv(vr[u]);
       if (MODE == 0) {
         acc += v * mk[u];
-      } else {
+      } else if (MODE == 1) {
         const f32x4 d = v - mean;
         acc += d * d * mk[u];
+      } else {
+        const f32x4 d = (v - mean) * mk[u];
+        acc += d;
+        acc2 += d * d;
       }
     }
   }
@@ -403,11 +413,26 @@ __global__ void __launch_bounds__(256) k_colstat4(const V4<T> x, const float* __
     const float t = red[0][cc][e] + red[1][cc][e] + red[2][cc][e] + red[3][cc][e];
     atomicAdd(out + (int64_t)(blockIdx.x % nslots) * slot_stride + threadIdx.x, t);
   }
+  if (MODE == 2) {
+    for (int off = C4; off < 64; off <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc2[e] += __shfl_xor(acc2[e], off, 64);
+    }
+    __syncthreads();
+    red[wave][lane] = acc2;
+    __syncthreads();
+    if (threadIdx.x < C4 * 4) {
+      const int cc = threadIdx.x >> 2, e = threadIdx.x & 3;
+      const float t = red[0][cc][e] + red[1][cc][e] + red[2][cc][e] + red[3][cc][e];
+      atomicAdd(out2 + (int64_t)(blockIdx.x % nslots) * slot_stride + threadIdx.x, t);
+    }
+  }
 }
 
 // false = shape not covered (C not a power-of-two multiple of 4 up to 256)
 bool launch_colstat_opt(int mode, const float* x, const float* msum, int msl, float inv_m, float* out, int nslots,
-                        int64_t slot_stride, int64_t M, int C, hipStream_t s, bool bf) {
+                        int64_t slot_stride, int64_t M, int C, hipStream_t s, bool bf, float* out2) {
+  if (mode == 2 && !out2) return false;
   if (C < 4 || C > 256 || (C & (C - 1))) return false;
   const int C4 = C / 4, nr = 256 / C4;
   int64_t rpb = 8 * nr;                                  // one unrolled trip per thread at least
@@ -417,12 +442,14 @@ bool launch_colstat_opt(int mode, const float* x, const float* msum, int msl, fl
   const int ns = nslots < 1 ? 1 : nslots;
   if (bf) {
     const V4<bf16_t> xv((const bf16_t*)x);
-    if (mode == 0) hipLaunchKernelGGL((k_colstat4<0, bf16_t>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb);
-    else hipLaunchKernelGGL((k_colstat4<1, bf16_t>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb);
+    if (mode == 0) hipLaunchKernelGGL((k_colstat4<0, bf16_t>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb, nullptr);
+    else if (mode == 1) hipLaunchKernelGGL((k_colstat4<1, bf16_t>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb, nullptr);
+    else hipLaunchKernelGGL((k_colstat4<2, bf16_t>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb, out2);
   } else {
     const V4<float> xv(x);
-    if (mode == 0) hipLaunchKernelGGL((k_colstat4<0, float>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb);
-    else hipLaunchKernelGGL((k_colstat4<1, float>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb);
+    if (mode == 0) hipLaunchKernelGGL((k_colstat4<0, float>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb, nullptr);
+    else if (mode == 1) hipLaunchKernelGGL((k_colstat4<1, float>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb, nullptr);
+    else hipLaunchKernelGGL((k_colstat4<2, float>), dim3(grid), dim3(256), 0, s, xv, msum, msl, inv_m, out, ns, slot_stride, M, C4, rpb, out2);
   }
   return true;
 }

@@ -922,22 +922,28 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
     x = blk.mn.out;
   }
   const int64_t M = (int64_t)B * sc.H * sc.W;
-  // batch statistics (two-pass, multiscale_vae.py:420-421): column sums, then squared deviations, each into
-  // kStatSlots slot copies that the finalize kernel folds
+  // batch statistics (multiscale_vae.py:420-421): one pass about a pivot (k_colstat4<2>, default) or two passes
+  // (MVAE_BN_ONEPASS=0: column sums, then squared deviations), each into kStatSlots slot copies that the finalize kernel folds
+  static const bool onepass = [] { const char* e = getenv("MVAE_BN_ONEPASS"); return e ? atoi(e) != 0 : true; }();
+  const float* pivot = nullptr;
   if (training) {
     launch_zero(sc.bn_sum, (int64_t)2 * h->stat_slots * sc.dc, s);            // bn_sum and bn_sqdev are adjacent
     // (x = the last block's output: float32 storage in either mode, see MN::out_f32)
-    const bool cs0 = launch_colstat_opt(0, x, nullptr, 0, 0.f, sc.bn_sum, h->stat_slots, sc.dc, M, sc.dc, s, false);
-    if (sc.bf) need16(h, cs0);
-    if (!cs0) launch_colsum(x, sc.bn_sum, M, sc.dc, s);
-    if (!launch_colstat_opt(1, x, sc.bn_sum, h->stat_slots, 1.0f / (float)M, sc.bn_sqdev, h->stat_slots, sc.dc, M, sc.dc, s, false)) {
-      launch_bn2d_mean(sc.bn_sum, nullptr, sc.bn_mean, M, sc.dc, 1, s);
-      launch_colsqdev(x, sc.bn_mean, sc.bn_sqdev, M, sc.dc, s);
+    if (onepass && launch_colstat_opt(2, x, nullptr, 0, 0.f, sc.bn_sum, h->stat_slots, sc.dc, M, sc.dc, s, false, sc.bn_sqdev)) {
+      pivot = x;                                                             // row 0 of x: the kernel's pivot
+    } else {
+      const bool cs0 = launch_colstat_opt(0, x, nullptr, 0, 0.f, sc.bn_sum, h->stat_slots, sc.dc, M, sc.dc, s, false);
+      if (sc.bf) need16(h, cs0);
+      if (!cs0) launch_colsum(x, sc.bn_sum, M, sc.dc, s);
+      if (!launch_colstat_opt(1, x, sc.bn_sum, h->stat_slots, 1.0f / (float)M, sc.bn_sqdev, h->stat_slots, sc.dc, M, sc.dc, s, false)) {
+        launch_bn2d_mean(sc.bn_sum, nullptr, sc.bn_mean, M, sc.dc, 1, s);
+        launch_colsqdev(x, sc.bn_mean, sc.bn_sqdev, M, sc.dc, s);
+      }
     }
   }
   launch_bn2d_finalize(sc.bn_sum, sc.bn_sqdev, P + sc.bn_g, P + sc.bn_b, h->ds + sc.st_bn_mean, h->ds + sc.st_bn_var,
                        sc.bn_mean, sc.bn_invstd, sc.bn_scale, sc.bn_shift, stats + sc.st_bn_mean,
-                       stats + sc.st_bn_var, M, sc.dc, kDecBnEps, training ? 1 : 0, h->stat_slots, s);
+                       stats + sc.st_bn_var, M, sc.dc, kDecBnEps, training ? 1 : 0, h->stat_slots, s, pivot);
   ProfScope ps("head_fwd", 4.0 * M * (sc.dc + sc.C), 2.0 * M * sc.dc * sc.C, s);
   const bool hf = launch_head_fwd(x, sc.bn_scale, sc.bn_shift, P + sc.out_w, P + sc.out_b, sc.y, M, sc.dc, sc.C, s, false);
   if (sc.bf) need16(h, hf);
