@@ -1458,7 +1458,8 @@ __device__ __forceinline__ bf16x8 frag_cols_at(const char* tile, int lane, int c
 template <int CI, int CO>
 __global__ void __launch_bounds__(256, 2) k16_wgrad_seg(const bf16_t* __restrict__ big, const bf16_t* __restrict__ small,
                                                         float* __restrict__ dW, float* __restrict__ db, ConvGeom g, int64_t M,
-                                                        int64_t rows_per_block) {
+                                                        int64_t rows_per_block, float* __restrict__ dbig, int nslots,
+                                                        int64_t slot_stride) {
   constexpr int KT = CI / 32, NT = CO / 32, TG = 5;
   constexpr int SEG = 67, HALF = 34, SROWS = 72;                     // staged pixels, even-pixel rows, rows reserved
   constexpr int TB = SROWS * CI * 2, TS = 32 * CO * 2, TILE = TB + TS;
@@ -1491,6 +1492,14 @@ __global__ void __launch_bounds__(256, 2) k16_wgrad_seg(const bf16_t* __restrict
   constexpr int PPI = 64 / CPX, NLB = (SEG + PPI - 1) / PPI, LG = CO / 16;
   const int lpx = lane / CPX, chx = lane % CPX;
   u32x4 xq[NLB], gq[LG];
+  // dbig != nullptr (a Conv2DTranspose's bias gradient = the column sums of `big`, PT = PL = 1, IH = 2 OH, IW = 2 OW): the blocks
+  // of kernel rows 1 and 2 meet every row of `big` exactly once (y = 2 oh + kh - 1), and the pixels q = 1 .. 64 of a tile's
+  // segment are the columns 2 ow0 .. 2 ow0 + 63 no other tile owns: their sum rides on the segment's way to LDS instead of a
+  // separate read pass over the tensor (k_colstat4).
+  const bool own_rows = dbig != nullptr && (kh == 1 || kh == 2);
+  float bacc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bacc[e] = 0.f;
   auto load_seg = [&](uint32_t row0) {                               // the tile's input row segment: 67 pixels from column 2 ow0 - PL
     const uint32_t ow0 = row0 % (uint32_t)g.OW, t2 = row0 / (uint32_t)g.OW;
     const int oh = (int)(t2 % (uint32_t)g.OH), bi = (int)(t2 / (uint32_t)g.OH);
@@ -1525,6 +1534,10 @@ __global__ void __launch_bounds__(256, 2) k16_wgrad_seg(const bf16_t* __restrict
     for (int u = 0; u < NLB; ++u) {
       const int q = u * PPI + lpx;
       if (q < SEG) *reinterpret_cast<u32x4*>(tb + tile_off<CI>((q & 1) * HALF + (q >> 1), chx)) = xq[u];
+      if (own_rows && q >= 1 && q <= 64) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bacc[2 * e] += bf16_lo(xq[u][e]); bacc[2 * e + 1] += bf16_hi(xq[u][e]); }
+      }
     }
     WAVE_LDS_SYNC16();
     if (row0 + 4 * 32 < m_end) { load_small(row0 + 4 * 32); load_seg(row0 + 4 * 32); }     // next tile in flight under the MFMAs
@@ -1576,6 +1589,20 @@ __global__ void __launch_bounds__(256, 2) k16_wgrad_seg(const bf16_t* __restrict
     __syncthreads();
     if (threadIdx.x < CO)
       atomicAdd(&db[threadIdx.x], red[threadIdx.x] + red[CO + threadIdx.x] + red[2 * CO + threadIdx.x] + red[3 * CO + threadIdx.x]);
+  }
+  if (own_rows) {                                          // lanes with the same channel chunk (lane % CPX) -> one sum; 4 waves -> LDS
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      for (int off = CPX; off < 64; off <<= 1) bacc[e] += __shfl_xor(bacc[e], off, 64);
+    __syncthreads();
+    if (lane < CPX) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave * CI + lane * 8 + e] = bacc[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < CI)
+      atomicAdd(&dbig[(int64_t)(blockIdx.x % (unsigned)nslots) * slot_stride + threadIdx.x],
+                red[threadIdx.x] + red[CI + threadIdx.x] + red[2 * CI + threadIdx.x] + red[3 * CI + threadIdx.x]);
   }
 }
 
@@ -2021,7 +2048,10 @@ bool launch16_taps(bool transposed, const void* in, const float* w, const float*
 }
 
 // convolution weight (+ bias) gradient.  false = shape not covered.
-bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s) {
+bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s,
+                    float* db_big, bool* db_big_done) {
+  if (db_big_done) *db_big_done = false;
+  const GradSlots sl_in = sl;
   const int64_t M = (int64_t)g.B * g.OH * g.OW;
   if (M * g.CO * 2 >= (1ll << 31) || (int64_t)g.B * g.IH * g.IW * g.CI * 2 >= (1ll << 31)) return false;
   if (!((g.CI == 32 && g.CO == 64) || (g.CI == 64 && g.CO == 32))) return false;
@@ -2042,10 +2072,15 @@ bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, co
   // 5 x 5, stride 2, SAME, output rows of whole 32-pixel tiles: the input row segment staged once per tile (k16_wgrad_seg)
   static const bool seg_on = [] { const char* e = getenv("MVAE_WGRAD_SEG16"); return e ? atoi(e) != 0 : true; }();
   if (!pointwise && seg_on && g.KH == 5 && g.SH == 2 && g.SW == 2 && g.OW % 32 == 0 && rpb % 32 == 0) {
+    // the bias gradient of a Conv2DTranspose (column sums of `big`) rides along: MVAE_WGRAD_DBIG16=0 leaves it to k_colstat4
+    static const bool dbig_on = [] { const char* e = getenv("MVAE_WGRAD_DBIG16"); return e ? atoi(e) != 0 : true; }();
+    float* dbg = (dbig_on && db_big && db_big_done && !det_mode() && g.PT == 1 && g.PL == 1 && g.IH == 2 * g.OH && g.IW == 2 * g.OW)
+                     ? sl_in.at(db_big) : nullptr;
     if (g.CI == 32) hipLaunchKernelGGL((k16_wgrad_seg<32, 64>), dim3(groups * 8u * g.KH), dim3(256), 0, s, (const bf16_t*)big,
-                                       (const bf16_t*)small, dW, db, g, M, rpb);
+                                       (const bf16_t*)small, dW, db, g, M, rpb, dbg, sl_in.count(), sl_in.stride);
     else hipLaunchKernelGGL((k16_wgrad_seg<64, 32>), dim3(groups * 8u * g.KH), dim3(256), 0, s, (const bf16_t*)big,
-                            (const bf16_t*)small, dW, db, g, M, rpb);
+                            (const bf16_t*)small, dW, db, g, M, rpb, dbg, sl_in.count(), sl_in.stride);
+    if (dbg) *db_big_done = true;
     return true;
   }
   if (g.CI == 32) { if (pointwise) MVAE_W16(32, 64, 1); else MVAE_W16(32, 64, 5); }

@@ -31,7 +31,8 @@ bool launch16_dual(const void* X, const float* W, const void* aux, const float* 
 bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g,
                    hipStream_t s, const float* w2 = nullptr, const float* bias2 = nullptr, void* out2 = nullptr,
                    bool* chained = nullptr);   // w2 / out2: the following block's conv0 rides along (T-form 32 -> 64)
-bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s);
+bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s,
+                    float* db_big = nullptr, bool* db_big_done = nullptr);
 }
 
 namespace {
@@ -1584,9 +1585,11 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
       if (blk.has_conv) {     // Conv2DTranspose: big = its output (d), small = its input (prev)
         ConvGeom g = blk.cg; g.B = B;
         if (sc.bf) {
-          need16(h, launch16_wgrad(d, prev, G + blk.cw, nullptr, g, h->gslots, s));
-          need16(h, launch_colstat_opt(0, d, nullptr, 0, 0.f, h->gslots.at(G + blk.cb), h->gslots.count(), h->gslots.stride,
-                                       (int64_t)B * g.IH * g.IW, g.CI, s, true));
+          bool db_done = false;                       // the bias gradient (column sums of d) inside the weight-gradient kernel
+          need16(h, launch16_wgrad(d, prev, G + blk.cw, nullptr, g, h->gslots, s, G + blk.cb, &db_done));
+          if (!db_done)
+            need16(h, launch_colstat_opt(0, d, nullptr, 0, 0.f, h->gslots.at(G + blk.cb), h->gslots.count(), h->gslots.stride,
+                                         (int64_t)B * g.IH * g.IW, g.CI, s, true));
         } else {
           hipStream_t w = wgrad_begin(h, sc, s, g.KH * g.KW > 1);
           launch_conv_wgrad(d, prev, G + blk.cw, nullptr, g, none, h->gslots, w);

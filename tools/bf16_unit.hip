@@ -18,7 +18,8 @@ bool launch16_dual(const void* X, const float* W, const void* aux, const float* 
 bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g,
                    hipStream_t s, const float* w2 = nullptr, const float* bias2 = nullptr, void* out2 = nullptr,
                    bool* chained = nullptr);
-bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s);
+bool launch16_wgrad(const void* big, const void* small, float* dW, float* db, const ConvGeom& g, GradSlots sl, hipStream_t s,
+                    float* db_big = nullptr, bool* db_big_done = nullptr);
 }
 static uint16_t f2b(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
 static float b2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
@@ -106,8 +107,14 @@ static void test_taps(int CI, int CO, int IH, int IW) {
       for (int ci = 0; ci < CI; ++ci) { double v = b2f(big[(((size_t)b * IH + y) * IW + x) * CI + ci]);
         for (int co = 0; co < CO; ++co) rw[((kh * 5 + kw) * CI + ci) * CO + co] += v * b2f(small[(((size_t)b * g.OH + oh) * g.OW + ow) * CO + co]); } } }
   float *gW, *gb; hipMalloc(&gW, rw.size() * 4); hipMalloc(&gb, CO * 4); hipMemset(gW, 0, rw.size() * 4); hipMemset(gb, 0, CO * 4);
-  GradSlots sl; ok = launch16_wgrad(dB, dS, gW, gb, g, sl, nullptr); hipDeviceSynchronize();
+  float* gbb; hipMalloc(&gbb, CI * 4); hipMemset(gbb, 0, CI * 4); bool bdone = false;      // column sums of `big` (a convT's bias gradient)
+  GradSlots sl; ok = launch16_wgrad(dB, dS, gW, gb, g, sl, nullptr, gbb, &bdone); hipDeviceSynchronize();
   printf("wgrad 5x5 %d,%d: launched=%d dW rel=%.3e db rel=%.3e\n", CI, CO, ok, relerr(rw, f2d(host(gW, rw.size()))), relerr(rbias, f2d(host(gb, CO))));
+  if (bdone) {
+    std::vector<double> rbb(CI, 0.0);
+    for (size_t i = 0; i < nb; ++i) rbb[i % CI] += b2f(big[i]);
+    printf("wgrad 5x5 %d,%d %dx%d big column sums: launched=1 db rel=%.3e\n", CI, CO, IH, IW, relerr(rbb, f2d(host(gbb, CI))));
+  }
 }
 static void test_wgrad_pw(int CI, int CO) {
   ConvGeom g{}; g.B = 3; g.IH = g.OH = 8; g.IW = g.OW = 12; g.CI = CI; g.CO = CO; g.KH = g.KW = g.SH = g.SW = 1;
