@@ -1593,6 +1593,8 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
         } else {
           hipStream_t w = wgrad_begin(h, sc, s, g.KH * g.KW > 1);
           launch_conv_wgrad(d, prev, G + blk.cw, nullptr, g, none, h->gslots, w);
+          // (the float32 5 x 5 weight-gradient kernel cannot take the bias gradient along as k16_wgrad_seg does: at 254 of 256
+          // registers, four more accumulating adds in its tap loop made hipcc spill 36 - 95 registers)
           if (!launch_colstat_opt(0, d, nullptr, 0, 0.f, h->gslots.at(G + blk.cb), h->gslots.count(), h->gslots.stride,
                                   (int64_t)B * g.IH * g.IW, g.CI, w))
             launch_colsum(d, G + blk.cb, (int64_t)B * g.IH * g.IW, g.CI, w);
