@@ -132,10 +132,13 @@ __device__ __forceinline__ void load_wfrags(const float* __restrict__ W, int r, 
 // Used where the consumer is a BatchNorm: the decoder's last block output keeps float32 storage, because normalisation
 // subtracts the batch mean and turns bf16's relative rounding error of the VALUE into (mean / std) times as much of the
 // normalised signal (measured: reconstruction RMS error 0.9 % of the range with a bf16 BatchNorm input).
-template <int N, bool RES, bool BIAS>
+// STATS: the lane also accumulates sum (v - pivot) and sum (v - pivot)^2 of what it stores (its 4 channels of quad q), for the
+// consumer BatchNorm's batch statistics (one pass about a pivot: k_colstat4<2>'s arithmetic without its read pass)
+template <int N, bool RES, bool BIAS, bool STATS = false>
 __device__ __forceinline__ void store_tile_t32(const f32x16 (&acc)[N / 32], const f32x4 (&bz)[N / 32][4],
                                                const char* __restrict__ res_tile, float* __restrict__ Y, int64_t row0, int r,
-                                               int h) {
+                                               int h, const f32x4 (*piv)[4] = nullptr, f32x4 (*a1)[4] = nullptr,
+                                               f32x4 (*a2)[4] = nullptr) {
   const int64_t rowoff = (row0 + r) * N;
 #pragma unroll
   for (int nt = 0; nt < N / 32; ++nt)
@@ -146,6 +149,11 @@ __device__ __forceinline__ void store_tile_t32(const f32x16 (&acc)[N / 32], cons
       if constexpr (BIAS) v += bz[nt][q];
       if constexpr (RES) v += unpack4(*reinterpret_cast<const uint2*>(res_tile + tile_off<N>(r, c0 >> 3) + (c0 & 7) * 2));
       *reinterpret_cast<f32x4*>(Y + rowoff + c0) = v;
+      if constexpr (STATS) {
+        const f32x4 d = v - piv[nt][q];
+        a1[nt][q] += d;
+        a2[nt][q] += d * d;
+      }
     }
 }
 
@@ -205,7 +213,9 @@ template <int K, int N, bool WT, bool GATE, bool RES, int ACT, bool OUT32 = fals
 __global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, const float* __restrict__ W,
                                               const float* __restrict__ bias, const float* __restrict__ gate,
                                               const bf16_t* __restrict__ res, void* __restrict__ Yv, int64_t ntiles,
-                                              int64_t rows_per_image) {
+                                              int64_t rows_per_image, const float* __restrict__ pivot = nullptr,
+                                              float* __restrict__ st1 = nullptr, float* __restrict__ st2 = nullptr, int nslots = 1,
+                                              int64_t slot_stride = 0) {
   constexpr int TB = 32 * K * 2, RB = RES ? 32 * N * 2 : 0;
   __shared__ __attribute__((aligned(16))) char lds[4 * (TB + RB)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -220,6 +230,18 @@ __global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, cons
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       bz[nt][q] = bias ? *reinterpret_cast<const f32x4*>(bias + nt * 32 + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // OUT32 with st1 != nullptr: per-channel sums of (y - pivot) and (y - pivot)^2 over everything this wave stores (the decoder
+  // BatchNorm's batch statistics without a pass over y): per-lane partials, folded over the 32 pixel lanes at the end
+  f32x4 piv[OUT32 ? N / 32 : 1][4], a1[OUT32 ? N / 32 : 1][4], a2[OUT32 ? N / 32 : 1][4];
+  if constexpr (OUT32) {
+#pragma unroll
+    for (int nt = 0; nt < N / 32; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        piv[nt][q] = pivot ? *reinterpret_cast<const f32x4*>(pivot + nt * 32 + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+        a1[nt][q] = a2[nt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t t = (int64_t)blockIdx.x * 4 + wave;
   TileRegs<K> cur, nxt;
@@ -265,11 +287,28 @@ __global__ void __launch_bounds__(256) k16_pw(const bf16_t* __restrict__ X, cons
 #pragma unroll
       for (int nt = 0; nt < N / 32; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][kk], xb, acc[nt], 0, 0, 0);
     }
-    if constexpr (OUT32) store_tile_t32<N, RES, true>(acc, bz, rtile, static_cast<float*>(Yv), row0, r, h);
+    if constexpr (OUT32) store_tile_t32<N, RES, true, true>(acc, bz, rtile, static_cast<float*>(Yv), row0, r, h, piv, a1, a2);
     else store_tile_t<N, RES, ACT, true>(acc, bz, rtile, static_cast<bf16_t*>(Yv), row0, r, h);
     cur = nxt;
     if constexpr (RES) rcur = rnxt;
     if constexpr (GATE) { gc0 = gn0; gc1 = gn1; }
+  }
+  if constexpr (OUT32) {
+    if (st1 != nullptr) {                                      // (kernel-uniform)
+      float* o1 = st1 + (int64_t)((blockIdx.x * 4 + wave) % (unsigned)nslots) * slot_stride;
+      float* o2 = st2 + (int64_t)((blockIdx.x * 4 + wave) % (unsigned)nslots) * slot_stride;
+#pragma unroll
+      for (int nt = 0; nt < N / 32; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float u = a1[nt][q][e], v = a2[nt][q][e];
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) { u += __shfl_xor(u, off, 64); v += __shfl_xor(v, off, 64); }
+            if (r == 0) { atomicAdd(o1 + nt * 32 + 8 * q + 4 * h + e, u); atomicAdd(o2 + nt * 32 + 8 * q + 4 * h + e, v); }
+          }
+    }
   }
 }
 
@@ -1614,7 +1653,8 @@ static int cus16() {
 
 // 1x1 convolution forward / transposed.  false = shape not covered.
 bool launch16_pw(bool transposed, const void* in, const float* w, const float* bias, const float* gate, const void* residual,
-                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s, bool out_f32) {
+                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s, bool out_f32,
+                 const float* pivot, float* st1, float* st2, int nslots, int64_t slot_stride) {
   if (M % 32 != 0 || M <= 0) return false;
   if (gate && (rows_per_image % 32 != 0)) return false;
   const int64_t ntiles = M / 32;
@@ -1626,14 +1666,15 @@ bool launch16_pw(bool transposed, const void* in, const float* w, const float* b
   if (out_f32) {                                 // the conv2 of a decoder's last block: gate + residual, float32 result
     if (!gate || !residual || transposed || act != ACT_NONE) return false;
     ProfScope ps("k16_pw", 2.0 * M * (K + N) + 4.0 * M * N, 2.0 * M * K * N, s);
-    if (K == 32 && N == 32) hipLaunchKernelGGL((k16_pw<32, 32, false, true, true, ACT_NONE, true>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image);
-    else if (K == 64 && N == 64) hipLaunchKernelGGL((k16_pw<64, 64, false, true, true, ACT_NONE, true>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image);
+    if (K == 32 && N == 32) hipLaunchKernelGGL((k16_pw<32, 32, false, true, true, ACT_NONE, true>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image, pivot, st1, st2, nslots < 1 ? 1 : nslots, slot_stride);
+    else if (K == 64 && N == 64) hipLaunchKernelGGL((k16_pw<64, 64, false, true, true, ACT_NONE, true>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image, pivot, st1, st2, nslots < 1 ? 1 : nslots, slot_stride);
     else return false;
     return true;
   }
   ProfScope ps("k16_pw", 2.0 * M * (K + N * (residual ? 2 : 1)), 2.0 * M * K * N, s);
 #define MVAE_PW1(KK, NN, WT_, G_, R_, A_)                                                                            \
-  hipLaunchKernelGGL((k16_pw<KK, NN, WT_, G_, R_, A_>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image)
+  hipLaunchKernelGGL((k16_pw<KK, NN, WT_, G_, R_, A_>), dim3(grid), dim3(256), 0, s, X, w, bias, gate, R, Y, ntiles, rows_per_image, \
+                     nullptr, nullptr, nullptr, 1, (int64_t)0)
 #define MVAE_PW(KK, NN, WT_)                                                                                          \
   if (K == KK && N == NN && transposed == WT_) {                                                                      \
     if (act != ACT_NONE && (act != ACT_RELU || gate || residual)) return false;                                       \

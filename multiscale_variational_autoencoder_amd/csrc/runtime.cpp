@@ -24,7 +24,8 @@ using namespace mvae;
 
 namespace mvae {      // kernels_bf16.hip
 bool launch16_pw(bool transposed, const void* in, const float* w, const float* bias, const float* gate, const void* residual,
-                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s, bool out_f32 = false);
+                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s, bool out_f32 = false,
+                 const float* pivot = nullptr, float* st1 = nullptr, float* st2 = nullptr, int nslots = 1, int64_t slot_stride = 0);
 bool launch16_dual(const void* X, const float* W, const void* aux, const float* gate, const void* residual, void* Y,
                    float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C, GradSlots sl,
                    hipStream_t s, bool embed_mask = false);
@@ -53,6 +54,13 @@ struct StateInfo { std::string name; int64_t elems, offset; float momentum; int6
 
 struct MN {
   bool out_f32 = false;                     // bf16 scale: this block's output feeds the decoder BatchNorm and stays float32
+  // set by decoder_forward on a decoder's LAST block (bf16 scale, training): the conv2 kernel that writes `out` also sums
+  // (out - pivot) and (out - pivot)^2 per channel into the BatchNorm's slot copies (no statistics pass over `out`)
+  const float* bn_piv = nullptr;
+  float *bn_s1 = nullptr, *bn_s2 = nullptr;
+  int bn_slots = 1;
+  int64_t bn_stride = 0;
+  bool bn_stats_done = false;
   int c = 0, H = 0, W = 0;
   int dg_slots = 1, dg_prefix = 0;          // slot copies of this block's gate gradient, and where they start in Scale::dg
   int64_t w0, b0, wd, bd, sw0, sb0, gam, bet, sw1, sb1, w2, b2;
@@ -706,7 +714,10 @@ int mn_forward(mvae_handle* h, MN& m, const float* x, int B, bool training, hipS
         launch16_pw_chain(m.t1, P + m.w2, P + m.b2, m.g, x, m.out, P + chain3->cw, P + chain3->cb, chain3->cout,
                           chain3_transposed, P + chain3->mn.w0, P + chain3->mn.b0, chain3->mn.t0, M, HW, c, s))
       return 2;
-    need16(h, launch16_pw(false, m.t1, P + m.w2, P + m.b2, m.g, x, m.out, M, HW, c, c, ACT_NONE, s, m.out_f32));
+    const bool st = m.out_f32 && m.bn_s1 != nullptr;
+    need16(h, launch16_pw(false, m.t1, P + m.w2, P + m.b2, m.g, x, m.out, M, HW, c, c, ACT_NONE, s, m.out_f32, st ? m.bn_piv : nullptr,
+                          st ? m.bn_s1 : nullptr, st ? m.bn_s2 : nullptr, m.bn_slots, m.bn_stride));
+    m.bn_stats_done = st;
     return 0;
   }
   if (chain && chain->c == c && chain->H == m.H && chain->W == m.W && mn_fwd_chain_split_kernel(B, m.H, m.W, c)) {
@@ -895,6 +906,23 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
   if (!fused_dd) launch_gemm_nn(sc.zs, P + sc.dd_w, P + sc.dd_b, sc.d0, nullptr, B, sc.z, (int)sc.K, ACT_NONE, s);
   const float* x = sc.d0;
   int chained = 0;
+  // batch statistics of the decoder BatchNorm (multiscale_vae.py:420-421), one pass about a pivot: on a bf16 scale the last
+  // block's conv2 kernel accumulates them while it writes its output (pivot = the previous step's batch mean, zero at bind:
+  // MVAE_BN_FUSED=0 switches that off); otherwise k_colstat4<2> reads the output once (pivot = its row 0; MVAE_BN_ONEPASS=0: the
+  // two-pass form, sums then squared deviations).  Slot copies are zeroed here, before the producer runs.
+  static const bool onepass = [] { const char* e = getenv("MVAE_BN_ONEPASS"); return e ? atoi(e) != 0 : true; }();
+  static const bool bn_fused = [] { const char* e = getenv("MVAE_BN_FUSED"); return e ? atoi(e) != 0 : true; }();
+  if (training) launch_zero(sc.bn_sum, (int64_t)2 * h->stat_slots * sc.dc, s);   // bn_sum and bn_sqdev are adjacent
+  {
+    MN& last = sc.dec.back().mn;
+    const bool fuse = training && onepass && bn_fused && sc.bf && last.out_f32 && !h->det;
+    last.bn_piv = fuse ? sc.bn_mean : nullptr;
+    last.bn_s1 = fuse ? sc.bn_sum : nullptr;
+    last.bn_s2 = fuse ? sc.bn_sqdev : nullptr;
+    last.bn_slots = h->stat_slots;
+    last.bn_stride = sc.dc;
+    last.bn_stats_done = false;
+  }
   for (Block& blk : sc.dec) {
     if (blk.has_conv && chained == 2) {
       x = blk.cout;                                   // computed by the previous block's conv2 launch
@@ -923,12 +951,10 @@ void decoder_forward(mvae_handle* h, Scale& sc, int B, bool training, hipStream_
     x = blk.mn.out;
   }
   const int64_t M = (int64_t)B * sc.H * sc.W;
-  // batch statistics (multiscale_vae.py:420-421): one pass about a pivot (k_colstat4<2>, default) or two passes
-  // (MVAE_BN_ONEPASS=0: column sums, then squared deviations), each into kStatSlots slot copies that the finalize kernel folds
-  static const bool onepass = [] { const char* e = getenv("MVAE_BN_ONEPASS"); return e ? atoi(e) != 0 : true; }();
   const float* pivot = nullptr;
-  if (training) {
-    launch_zero(sc.bn_sum, (int64_t)2 * h->stat_slots * sc.dc, s);            // bn_sum and bn_sqdev are adjacent
+  if (training && sc.dec.back().mn.bn_stats_done) {
+    pivot = sc.bn_mean;                                                      // (the finalize kernel reads it before it stores the mean)
+  } else if (training) {
     // (x = the last block's output: float32 storage in either mode, see MN::out_f32)
     if (onepass && launch_colstat_opt(2, x, nullptr, 0, 0.f, sc.bn_sum, h->stat_slots, sc.dc, M, sc.dc, s, false, sc.bn_sqdev)) {
       pivot = x;                                                             // row 0 of x: the kernel's pivot
@@ -1314,6 +1340,8 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   h->device = device;
   h->dp = params; h->dr = reduce_arena; h->da = accum; h->ds = state; h->ws = static_cast<float*>(workspace);
   rebase_all(h);
+  for (Scale& sc : h->scales)                                                 // the first step's pivot of the fused BatchNorm statistics
+    if (sc.bn_mean) (void)hipMemset(sc.bn_mean, 0, sizeof(float) * sc.dc);
   h->gslots.gbase = h->dr;
   if (const char* v = getenv("MVAE_GRAD_SLOTS")) { if (!h->det) h->gslots.n = atoi(v) > 0 && atoi(v) <= kGradSlots ? atoi(v) : 0; }
   e = hipMemcpy(h->d_chunks, h->chunks.data(), h->chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);

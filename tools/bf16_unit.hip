@@ -12,7 +12,8 @@
 using namespace mvae;
 namespace mvae {
 bool launch16_pw(bool transposed, const void* in, const float* w, const float* bias, const float* gate, const void* residual,
-                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s, bool out_f32 = false);
+                 void* out, int64_t M, int64_t rows_per_image, int K, int N, int act, hipStream_t s, bool out_f32 = false,
+                 const float* pivot = nullptr, float* st1 = nullptr, float* st2 = nullptr, int nslots = 1, int64_t slot_stride = 0);
 bool launch16_dual(const void* X, const float* W, const void* aux, const float* gate, const void* residual, void* Y,
                    float* dW, float* db, float* dot_out, int64_t M, int64_t rows_per_image, int C, GradSlots sl, hipStream_t s, bool embed_mask = false);
 bool launch16_taps(bool transposed, const void* in, const float* w, const float* bias, void* out, const ConvGeom& g,
