@@ -29,6 +29,8 @@ def test_bf16_kernels_one_by_one():
         for k, v in vals.items():
             if k in ("dW", "db"):
                 bound = 1e-6                     # exact products, float32 sums
+            elif k in ("mean", "var"):
+                bound = 2e-5                     # one-pass statistics about a pivot: mean in units of sigma, variance relative
             elif k == "dot":
                 bound = 1e-5
             elif ln.startswith("dual") and "mode=1" in ln:

@@ -150,7 +150,14 @@ def test_multi_image_blocks_parity(name, B, det):
     assert "fused launches: fwd" in out and "images per block" in out, out[-2000:]
 
 
-if __name__ == "__main__":          # subprocess body of test_multi_image_blocks_parity
+def test_two_pass_batchnorm_statistics_parity():
+    """MVAE_BN_ONEPASS=0: the decoder BatchNorm's batch statistics as two passes (sums, then squared deviations) -- the form the
+    default one-pass kernels (k_colstat4<2>; the conv2 kernel's fused sums on bf16 scales) replaced, kept as their fallback."""
+    out = _subprocess_case("c32nb", 20, "twopass_bn_c32nb_b20", dict(MULTI_IMAGE_ENV, MVAE_BN_ONEPASS="0"))
+    assert "ok twopass_bn_c32nb_b20" in out, out[-2000:]
+
+
+if __name__ == "__main__":          # subprocess body of test_multi_image_blocks_parity / test_two_pass_batchnorm_statistics_parity
     import sys
     _name, _B, _tag = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 

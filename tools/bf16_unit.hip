@@ -117,6 +117,27 @@ static void test_taps(int CI, int CO, int IH, int IW) {
     printf("wgrad 5x5 %d,%d %dx%d big column sums: launched=1 db rel=%.3e\n", CI, CO, IH, IW, relerr(rbb, f2d(host(gbb, CI))));
   }
 }
+// one-pass column statistics about a pivot (k_colstat4<2> + k_bn2d_finalize), float32 input: the adverse case of a column
+// whose mean is `off` standard deviations away from zero (E[x^2] - E[x]^2 would lose log2(off^2) bits; the pivot is a sample)
+static void test_colstat(int64_t M, int C, float off) {
+  std::vector<float> x((size_t)M * C); for (auto& v : x) v = off + 0.5f * rnd();
+  std::vector<double> mu(C, 0.0), var(C, 0.0);
+  for (int64_t m = 0; m < M; ++m) for (int c = 0; c < C; ++c) mu[c] += x[m * C + c];
+  for (int c = 0; c < C; ++c) mu[c] /= (double)M;
+  for (int64_t m = 0; m < M; ++m) for (int c = 0; c < C; ++c) { const double d = x[m * C + c] - mu[c]; var[c] += d * d; }
+  for (int c = 0; c < C; ++c) var[c] /= (double)M;
+  auto dx = dev(x); const int ns = 16;
+  std::vector<float> ones(C, 1.f), zeros(C, 0.f); auto dg = dev(ones); auto dbt = dev(zeros);
+  float *st, *o; hipMalloc(&st, 2 * ns * C * 4); hipMemset(st, 0, 2 * ns * C * 4); hipMalloc(&o, 8 * C * 4);
+  bool ok = launch_colstat_opt(2, dx, nullptr, 0, 0.f, st, ns, C, M, C, nullptr, false, st + ns * C);
+  launch_bn2d_finalize(st, st + ns * C, dg, dbt, dbt, dbt, o, o + C, o + 2 * C, o + 3 * C, o + 4 * C, o + 5 * C, M, C, 1e-4f, 1, ns, nullptr, dx);
+  hipDeviceSynchronize();
+  auto got = host(o, 8 * C);
+  std::vector<double> gm(got.begin() + 4 * C, got.begin() + 5 * C), gv(got.begin() + 5 * C, got.begin() + 6 * C);
+  // the mean is compared on the scale of the standard deviation (what the normalisation sees), the variance relatively
+  double em = 0; for (int c = 0; c < C; ++c) em = std::max(em, std::fabs(gm[c] - mu[c]) / std::sqrt(var[c]));
+  printf("colstat one-pass M=%lld C=%d offset=%g: launched=%d mean rel=%.3e var rel=%.3e\n", (long long)M, C, off, ok, em, relerr(var, gv));
+}
 static void test_wgrad_pw(int CI, int CO) {
   ConvGeom g{}; g.B = 3; g.IH = g.OH = 8; g.IW = g.OW = 12; g.CI = CI; g.CO = CO; g.KH = g.KW = g.SH = g.SW = 1;
   const int64_t M = (int64_t)g.B * 96; std::vector<uint16_t> big(M * CI), small(M * CO);
@@ -171,6 +192,7 @@ int main(int argc, char** argv) {
   test_taps(32, 64, 16, 16); test_taps(64, 32, 16, 16); test_taps(32, 64, 12, 20);
   test_taps(32, 64, 8, 64); test_taps(64, 32, 8, 64); test_taps(32, 64, 6, 128); test_taps(64, 32, 10, 128);   // OW = 32 / 64: k16_wgrad_seg, k16_taps_fr<.., 32>
   test_wgrad_pw(64, 32); test_wgrad_pw(32, 64);
+  test_colstat(200000, 32, 0.f); test_colstat(200000, 32, 100.f); test_colstat(65536, 64, -30.f);
   printf("last hip error: %s\n", hipGetErrorString(hipGetLastError()));
   return 0;
 }
