@@ -44,6 +44,8 @@ enum { HP_RF_OVER_B = 0, HP_KF_OVER_B = 1, HP_LR = 2, HP_CLIP = 3, HP_GRAD_SCALE
 void launch_set_f3(float* dst, float a, float b, float c, int n, hipStream_t s);
 void launch_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t n, int64_t row_elems, hipStream_t s);
 void launch_rng_normal(float* out, int64_t n, float stddev, const uint64_t* seed, uint32_t stream_id, hipStream_t s);
+void launch_rng_step(float* eps, int64_t n_eps, float std_eps, float* noise, int64_t n_noise, float* keep, int64_t n_keep,
+                     float p_drop, float* zero_buf, int64_t n_zero, const uint64_t* seed, hipStream_t s);
 void launch_rng_keepmask(float* out, int64_t n, float p_drop, const uint64_t* seed, uint32_t stream_id, hipStream_t s);
 
 // ---- input transform (multiscale_vae.py:129-160, 292-315) ----

@@ -100,6 +100,46 @@ __global__ void k_rng_keepmask(float* out, int64_t n, float p_drop, const uint64
       if (i * 4 + j < n) out[i * 4 + j] = u01(v[j]) >= p_drop ? 1.f : 0.f;
   }
 }
+// The random draws of a training step in ONE launch (round 4; three launches + a zero fill sat serially at the head of every
+// forward pass): eps (stream 1), input noise (stream 2), dropout keep mask (stream 3) -- element for element what
+// k_rng_normal / k_rng_keepmask produce -- and the zeroed metrics vector.
+__global__ void k_rng_step(float* eps, int64_t n_eps, float std_eps, float* noise, int64_t n_noise, float* keep, int64_t n_keep,
+                           float p_drop, float* zero_buf, int64_t n_zero, const uint64_t* seed_ptr) {
+  const uint64_t seed = *seed_ptr;
+  const int64_t q0 = (n_eps + 3) / 4, q1 = q0 + (n_noise + 3) / 4, q2 = q1 + (n_keep + 3) / 4, q3 = q2 + (n_zero + 3) / 4;
+  GRID_STRIDE(t, q3) {
+    if (t < q1) {
+      const bool first = t < q0;
+      const int64_t i = first ? t : t - q0, n = first ? n_eps : n_noise;
+      float* out = first ? eps : noise;
+      const float sd = first ? std_eps : 1.0f;
+      U4 r = philox((uint64_t)i, first ? 1u : 2u, seed);
+      float a0 = sqrtf(-2.f * __logf(u01(r.x))), a1 = sqrtf(-2.f * __logf(u01(r.z)));
+      float t0 = 6.2831853071795865f * u01(r.y), t1 = 6.2831853071795865f * u01(r.w);
+      float v[4] = {a0 * __cosf(t0), a0 * __sinf(t0), a1 * __cosf(t1), a1 * __sinf(t1)};
+      for (int j = 0; j < 4; ++j)
+        if (i * 4 + j < n) out[i * 4 + j] = v[j] * sd;
+    } else if (t < q2) {
+      const int64_t i = t - q1;
+      U4 r = philox((uint64_t)i, 3u, seed);
+      uint32_t v[4] = {r.x, r.y, r.z, r.w};
+      for (int j = 0; j < 4; ++j)
+        if (i * 4 + j < n_keep) keep[i * 4 + j] = u01(v[j]) >= p_drop ? 1.f : 0.f;
+    } else {
+      const int64_t i = t - q2;
+      for (int j = 0; j < 4; ++j)
+        if (i * 4 + j < n_zero) zero_buf[i * 4 + j] = 0.f;
+    }
+  }
+}
+void launch_rng_step(float* eps, int64_t n_eps, float std_eps, float* noise, int64_t n_noise, float* keep, int64_t n_keep,
+                     float p_drop, float* zero_buf, int64_t n_zero, const uint64_t* seed, hipStream_t s) {
+  ProfScope ps("rng", (double)(4.0 * (n_eps + n_noise + n_keep)), 0.0, s);
+  const int64_t q = (n_eps + 3) / 4 + (n_noise + 3) / 4 + (n_keep + 3) / 4 + (n_zero + 3) / 4;
+  if (q <= 0) return;
+  hipLaunchKernelGGL(k_rng_step, dim3(grid_for(q)), dim3(kBlock), 0, s, eps, n_eps, std_eps, noise, n_noise, keep, n_keep, p_drop,
+                     zero_buf, n_zero, seed);
+}
 void launch_rng_normal(float* out, int64_t n, float stddev, const uint64_t* seed, uint32_t sid, hipStream_t s) {
   ProfScope ps("rng", (double)(4.0*n), 0.0, s);
   if (n <= 0) return;

@@ -145,6 +145,10 @@ struct mvae_handle {
         *losses = nullptr, *sgn = nullptr, *reg_tmp = nullptr;
   uint64_t* d_seed = nullptr;
   float* d_hp = nullptr;                    // kernels.h HP_*: loss factors, lr, clip, grad_scale (device-resident)
+  // what the hyper-parameter block was last set to, and on which stream: a training loop passes the same values step after
+  // step, and each update is an eager one-thread launch between two graph replays
+  float hp_set[5] = {NAN, NAN, NAN, NAN, NAN};
+  hipStream_t hp_stream[2] = {nullptr, nullptr};
   int64_t off_seed = 0, off_hp = 0, off_stamps = 0;
   uint64_t* d_stamps = nullptr;             // MVAE_STAMPS=1: device time stamps at the forks / joins of a step (diagnostic)
   bool stamps = false;
@@ -1435,14 +1439,20 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
   auto body = [=](hipStream_t s) {
     stamp(h, 0, s);
     const mvae_step_io* io = &io_c;
-    launch_zero(metrics, (int64_t)(h->MET), s);
-    // ---- randomness: injected (parity) or Philox on the device (timed runs)
-    if (!io->eps) launch_rng_normal(h->eps_buf, (int64_t)B * h->Z, c.sample_std, h->d_seed, 1u, s);
+    // ---- randomness: injected (parity) or Philox on the device (timed runs: all three draws and the zeroed metrics in one launch)
     const float *noise = nullptr, *keep = nullptr;
-    if (training) {
-      noise = io->noise; keep = io->keep_mask;
-      if (!noise) { launch_rng_normal(h->noise_buf, hwC * B, 1.0f, h->d_seed, 2u, s); noise = h->noise_buf; }
-      if (!keep) { launch_rng_keepmask(h->keep_buf, (int64_t)B * C, kDropout, h->d_seed, 3u, s); keep = h->keep_buf; }
+    if (training && !io->eps && !io->noise && !io->keep_mask) {
+      launch_rng_step(h->eps_buf, (int64_t)B * h->Z, c.sample_std, h->noise_buf, hwC * B, h->keep_buf, (int64_t)B * C, kDropout,
+                      metrics, (int64_t)(h->MET), h->d_seed, s);
+      noise = h->noise_buf; keep = h->keep_buf;
+    } else {
+      launch_zero(metrics, (int64_t)(h->MET), s);
+      if (!io->eps) launch_rng_normal(h->eps_buf, (int64_t)B * h->Z, c.sample_std, h->d_seed, 1u, s);
+      if (training) {
+        noise = io->noise; keep = io->keep_mask;
+        if (!noise) { launch_rng_normal(h->noise_buf, hwC * B, 1.0f, h->d_seed, 2u, s); noise = h->noise_buf; }
+        if (!keep) { launch_rng_keepmask(h->keep_buf, (int64_t)B * C, kDropout, h->d_seed, 3u, s); keep = h->keep_buf; }
+      }
     }
     // ---- input transform (multiscale_vae.py:129-160)
     launch_prep(xsrc, noise, keep, h->scales[0].pcur, B, c.input_h, c.input_w, C, c.min_value, c.max_value,
@@ -1549,7 +1559,13 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
   h->kernel_gap = false;
   set_det_mode(h->det);
   // loss factors go through the device hyper-parameter block: the captured graph does not depend on their values
-  launch_set_f3(h->d_hp + HP_RF_OVER_B, r_factor / (float)B, kl_factor / (float)B, 0.f, 2, s0);
+  {
+    const float a = r_factor / (float)B, b = kl_factor / (float)B;
+    if (!(h->hp_set[0] == a && h->hp_set[1] == b && h->hp_stream[0] == s0)) {
+      launch_set_f3(h->d_hp + HP_RF_OVER_B, a, b, 0.f, 2, s0);
+      h->hp_set[0] = a; h->hp_set[1] = b; h->hp_stream[0] = s0;
+    }
+  }
   // phase bit 1: loss, decoder halves, Dense gradients (everything that fills the leading arena region);
   // phase bit 2: encoder halves, conv_base, gradient-slot fold.  3 = the whole pass in one graph.
   auto body = [=](hipStream_t s) {
@@ -1787,7 +1803,10 @@ int mvae_apply_adagrad(mvae_handle* h, float lr, float clip_norm, float grad_sca
   set_det_mode(h->det);                     // (process-global launcher switch: every entry point sets it from ITS handle)
   const int Bt = h->last_train_B;
   const bool clip = clip_norm > 0.f;
-  launch_set_f3(h->d_hp + HP_LR, lr, clip_norm, grad_scale, 3, s0);     // HP_LR, HP_CLIP, HP_GRAD_SCALE are adjacent
+  if (!(h->hp_set[2] == lr && h->hp_set[3] == clip_norm && h->hp_set[4] == grad_scale && h->hp_stream[1] == s0)) {
+    launch_set_f3(h->d_hp + HP_LR, lr, clip_norm, grad_scale, 3, s0);   // HP_LR, HP_CLIP, HP_GRAD_SCALE are adjacent
+    h->hp_set[2] = lr; h->hp_set[3] = clip_norm; h->hp_set[4] = grad_scale; h->hp_stream[1] = s0;
+  }
   auto body = [=](hipStream_t s) {
     stamp(h, 8, s);
     launch_opt_prepare(h->dp, h->dr, h->d_chunks, (int)h->chunks.size(), h->d_norms, h->d_hp, s);
