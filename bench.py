@@ -241,7 +241,8 @@ def secondary_workload(wname, local, torch, dist, lr, rf, kf, clip, profile=True
     H, Wd, C = w["input_dims"]
     e = Engine(w["input_dims"], w["z_dims"], w["encoder"], w["decoder"], 0.0, 255.0, 0.01, B, act_dtype=act).bind(local)
     e.set_params(init_params(e.param_table, 42))
-    x = e.to_device(np.random.default_rng(77).uniform(0, 255, (B, H, Wd, C)))
+    # (synthetic batch, resident in the handle's own input buffer: Engine.stage_input -- a training loop gathers into it)
+    x = e.stage_input(e.to_device(np.random.default_rng(77).uniform(0, 255, (B, H, Wd, C))))
     st = lambda i: e.train_step(x, lr, rf, kf, clip, seed=9000 + i)
     for i in range(3):
         st(i)
@@ -321,7 +322,9 @@ def main():
     eng = Engine(w["input_dims"], w["z_dims"], w["encoder"], w["decoder"], 0.0, 255.0, 0.01, B, act_dtype=act).bind(local)
     eng.set_params(init_params(eng.param_table, 42))          # identical replicas on every rank
     H, Wd, C = w["input_dims"]
-    x = eng.to_device(np.random.default_rng(1234 + rank).uniform(0, 255, (B, H, Wd, C)))
+    # the synthetic batch lives in the handle's own input buffer (Engine.stage_input): a training loop gathers every batch
+    # straight into it (Engine.gather_batch), so no step pays a device-to-device copy of its input
+    x = eng.stage_input(eng.to_device(np.random.default_rng(1234 + rank).uniform(0, 255, (B, H, Wd, C))))
     lr, rf, kf, clip = 1e-3, 1000.0, 10.0, 1.0
     coll_timing = []
     collective = eng.collective_active(args.force_collective)
@@ -378,7 +381,7 @@ def main():
     if world == 1 and args.workload == "c32nb" and not args.no_secondary and not args.batch:
         e2 = Engine(w["input_dims"], w["z_dims"], w["encoder"], w["decoder"], 0.0, 255.0, 0.01, 128, act_dtype=act).bind(local)
         e2.set_params(init_params(e2.param_table, 42))
-        x2 = e2.to_device(np.random.default_rng(99).uniform(0, 255, (128, H, Wd, C)))
+        x2 = e2.stage_input(e2.to_device(np.random.default_rng(99).uniform(0, 255, (128, H, Wd, C))))
         s2 = lambda i: e2.train_step(x2, lr, rf, kf, clip, seed=7000 + i)
         for i in range(5):
             s2(i)
@@ -391,7 +394,8 @@ def main():
             # config 2 is float32) -- its own algorithmic bytes (2 bytes per activation element)
             e3 = Engine(w["input_dims"], w["z_dims"], w["encoder"], w["decoder"], 0.0, 255.0, 0.01, B, act_dtype="bf16").bind(local)
             e3.set_params(init_params(e3.param_table, 42))
-            s3 = lambda i: e3.train_step(x, lr, rf, kf, clip, seed=8000 + i)
+            x3 = e3.stage_input(x)
+            s3 = lambda i: e3.train_step(x3, lr, rf, kf, clip, seed=8000 + i)
             for i in range(5):
                 s3(i)
             dt3, per3 = timed_steps(e3, lambda i: s3(100 + i), 30, torch, dist, 1)

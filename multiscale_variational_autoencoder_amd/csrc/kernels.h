@@ -36,6 +36,7 @@ void set_det_mode(bool on);
 // the seed is read from DEVICE memory so that a captured hipGraph stays valid from step to step
 void launch_set_u64(uint64_t* dst, uint64_t v, hipStream_t s);
 void launch_stamp(uint64_t* dst, hipStream_t s);
+void launch_seed_next(uint64_t* p, hipStream_t s);
 void launch_zero(float* p, int64_t n, hipStream_t s);
 // Hyper-parameters live in a small DEVICE block (like the seed), written by a one-thread kernel ahead of the graph
 // launch: one captured hipGraph then serves every learning rate / loss factor (a step-decay schedule used to

@@ -155,6 +155,8 @@ void launch_zero(float* p, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_zero, dim3(grid_for(n)), dim3(kBlock), 0, s, p, n);
 }
 __global__ void k_set_u64(uint64_t* dst, uint64_t v) { *dst = v; }
+__global__ void k_seed_next(uint64_t* p) { *p += 1; }
+void launch_seed_next(uint64_t* p, hipStream_t s) { hipLaunchKernelGGL(k_seed_next, dim3(1), dim3(1), 0, s, p); }
 // the constant-frequency (100 MHz) device clock -> *dst (diagnostic time stamps inside replayed graphs: runtime.cpp stamp())
 __global__ void k_stamp(uint64_t* dst) { *dst = wall_clock64(); }
 void launch_stamp(uint64_t* dst, hipStream_t s) { hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, s, dst); }

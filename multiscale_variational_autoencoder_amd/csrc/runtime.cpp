@@ -148,6 +148,11 @@ struct mvae_handle {
   // what the hyper-parameter block was last set to, and on which stream: a training loop passes the same values step after
   // step, and each update is an eager one-thread launch between two graph replays
   float hp_set[5] = {NAN, NAN, NAN, NAN, NAN};
+  // the forward pass leaves seed + 1 in d_seed (k_seed_next, inside the graph): a caller that counts its seeds up step by step --
+  // every training loop -- needs no eager launch to set it
+  uint64_t seed_dev = 0;
+  bool seed_dev_valid = false;
+  hipStream_t seed_stream = nullptr;
   hipStream_t hp_stream[2] = {nullptr, nullptr};
   int64_t off_seed = 0, off_hp = 0, off_stamps = 0;
   uint64_t* d_stamps = nullptr;             // MVAE_STAMPS=1: device time stamps at the forks / joins of a step (diagnostic)
@@ -1430,10 +1435,13 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
                           !io->z && !io->losses;
   const float* xsrc = io->x;
   if (replayable && h->use_graphs && !profiler().on && s0 != nullptr) {
-    (void)hipMemcpyAsync(h->xin, io->x, sizeof(float) * hwC * B, hipMemcpyDeviceToDevice, s0);
+    // (a caller that wrote the batch straight into the handle's input buffer -- mvae_tensor_lookup("xin"), Engine.input_buffer --
+    // passes that pointer and saves this copy: an eager launch between two graph replays costs ~15 us of every step)
+    if (io->x != h->xin) (void)hipMemcpyAsync(h->xin, io->x, sizeof(float) * hwC * B, hipMemcpyDeviceToDevice, s0);
     xsrc = h->xin;
   }
-  launch_set_u64(h->d_seed, io->seed, s0);
+  if (!(h->seed_dev_valid && h->seed_dev == io->seed && h->seed_stream == s0)) launch_set_u64(h->d_seed, io->seed, s0);
+  h->seed_dev_valid = false;                      // (valid again once this pass -- and its k_seed_next -- is enqueued)
   const float* eps = io->eps ? io->eps : h->eps_buf;
 
   auto body = [=](hipStream_t s) {
@@ -1454,6 +1462,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
         if (!keep) { launch_rng_keepmask(h->keep_buf, (int64_t)B * C, kDropout, h->d_seed, 3u, s); keep = h->keep_buf; }
       }
     }
+    launch_seed_next(h->d_seed, s);                              // d_seed <- seed + 1 (after this pass's draws: same stream)
     // ---- input transform (multiscale_vae.py:129-160)
     launch_prep(xsrc, noise, keep, h->scales[0].pcur, B, c.input_h, c.input_w, C, c.min_value, c.max_value,
                 1.0f / (c.max_value - c.min_value), 1.0f / (1.0f - kDropout), s);
@@ -1540,6 +1549,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
   if (replayable && xsrc == h->xin) rc = run_captured(h, fkey("F:%d:%d", B, training ? 1 : 0), s0, body);
   else body(s0);
   if (rc != MVAE_OK) return rc;
+  h->seed_dev = io->seed + 1; h->seed_dev_valid = true; h->seed_stream = s0;
   h->last_B = B; h->last_training = training; h->last_x = xsrc; h->last_eps = eps;
   if (training) h->last_train_B = B;
   if (h->kernel_gap) return fail(h, MVAE_E_INVALID, "mvae_forward: a bfloat16 launch found no kernel for its shape");

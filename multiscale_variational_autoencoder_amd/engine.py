@@ -412,6 +412,24 @@ class Engine:
         else:
             ds["perm"] = order
 
+    def input_buffer(self, batch):
+        """[batch,H,W,C] float32 view of the handle's own input buffer.  A batch written here and passed to forward() /
+        train_step() is read in place: the library otherwise copies every batch into this buffer first (its captured graphs
+        need a stable address), an eager launch between two graph replays."""
+        p, n, dt = C.c_void_p(), C.c_int64(), C.c_int32()
+        self._check_rc(self.lib.mvae_tensor_lookup2(self.h, b"xin", C.byref(p), C.byref(n), C.byref(dt)))
+        off = (p.value - self.workspace.data_ptr()) // 4
+        if batch > self.max_batch:
+            raise ValueError("batch %d exceeds the engine's max_batch %d" % (batch, self.max_batch))
+        return self.workspace[off:off + batch * n.value].view((batch,) + tuple(self.input_dims))
+
+    def stage_input(self, x):
+        """Copy a batch into the handle's input buffer once and return that view (for a caller that feeds the SAME batch to
+        many steps, as a benchmark on synthetic data does; a training loop gathers every batch straight into input_buffer())."""
+        v = self.input_buffer(int(x.shape[0]))
+        v.copy_(x)
+        return v
+
     def gather_batch(self, start, count):
         """Device tensor [count,H,W,C] = dataset[perm[start:start+count]], ready on self.stream."""
         ds, torch = self.dataset, self.torch
@@ -419,6 +437,7 @@ class Engine:
         ds["tick"] += 1
         out = ds["buf"][k][:count]
         if ds["resident"]:
+            out = self.input_buffer(count)         # gathered straight into the handle's input buffer (same stream as the step)
             idx = ds["perm"][start:start + count]
             self._check_rc(self.lib.mvae_gather_rows(self.device.index, _ptr(ds["data"]), _ptr(idx), count, ds["row"],
                                                      _ptr(out), self._stream()))
