@@ -166,6 +166,15 @@ struct mvae_handle {
   // correct in eager mode, but the ~450 extra event calls per step make the host the bottleneck there, and a fork from a
   // stream that itself joined the capture by a fork crashes hipStreamEndCapture (ROCm 7.2), so that mode never captures.
   bool merge_side = false;
+  // side streams actually used: scale l runs on side[min(l, side_cap)].  A process has 4 hardware queues (GPU_MAX_HW_QUEUES), and a
+  // forked graph's branches are dealt onto them in creation order: with the 7 scales of a 256 x 256 model as 7 branches, scales
+  // 0 / 1 / 2 each queued behind one of the small scales' whole chains (in-graph stamps: scale 0 started 0.47 ms after the
+  // forward's fork and 0.97 ms after the backward's).  MVAE_SIDE_STREAMS=3 makes exactly 4 branches (scales >= 3 one after the
+  // other on the last side stream): measured SLOWER (20.5 against 20.2 ms) -- beside the big scales' kernels the small chains
+  // take 2 - 5x as long.  Default: one stream per scale; the ISSUE ORDER (issue_order, set in mvae_create) decides who queues
+  // behind whom.
+  int side_cap = MVAE_MAX_LEVELS;
+  int issue_order[MVAE_MAX_LEVELS] = {};   // the order in which the scales' chains are issued (= captured = dealt onto hardware queues)
   bool multi_stream = true, use_graphs = true;
   int wgrad_streams = 0;
   bool lsb_mask = true;                     // the depthwise backward takes the ReLU mask from the LSB of dt2 (MVAE_LSB_MASK=0: reads t1)
@@ -1008,7 +1017,8 @@ static bool serial_scales(mvae_handle* h) {
 }
 hipStream_t scale_stream(mvae_handle* h, int scale, hipStream_t main) {
   if (serial_scales(h) || scale == 0) return main;
-  return h->side[h->merge_side ? 1 : scale];
+  if (h->merge_side) return h->side[1];
+  return h->side[scale < h->side_cap ? scale : h->side_cap];
 }
 // TIMING DIAGNOSTIC ONLY (tools/chain_only.py): MVAE_DEBUG_ONLY_SCALE=k launches the kernels of scale k alone -- the
 // results are then garbage; it prices one scale's chain without the others beside it.  The release library does not
@@ -1078,23 +1088,23 @@ void fork_scales(mvae_handle* h, hipStream_t main) {
   if (h->segcap) {                          // the graph of what came before ends here; the fork is replayed eagerly
     seg_end(h, main);
     h->segcap->push_back({1, nullptr, 0, h->ev_fork});
-    for (int l = 1; l < h->cfg.levels; ++l) h->segcap->push_back({2, nullptr, l, h->ev_fork});
+    for (int l = 1; l < h->cfg.levels && l <= h->side_cap; ++l) h->segcap->push_back({2, nullptr, l, h->ev_fork});
     return;
   }
   (void)hipEventRecord(h->ev_fork, main);
-  for (int l = 1; l < h->cfg.levels; ++l) (void)hipStreamWaitEvent(h->side[l], h->ev_fork, 0);
+  for (int l = 1; l < h->cfg.levels && l <= h->side_cap; ++l) (void)hipStreamWaitEvent(h->side[l], h->ev_fork, 0);
 }
 void join_scales(mvae_handle* h, hipStream_t main) {
   if (serial_scales(h)) return;
   if (h->segcap) {
-    for (int l = 1; l < h->cfg.levels; ++l) {
+    for (int l = 1; l < h->cfg.levels && l <= h->side_cap; ++l) {
       h->segcap->push_back({1, nullptr, l, h->ev_join[l]});
       h->segcap->push_back({2, nullptr, 0, h->ev_join[l]});
     }
     seg_begin(h, main);                     // what follows the join: one more linear graph on the caller's stream
     return;
   }
-  for (int l = 1; l < h->cfg.levels; ++l) {
+  for (int l = 1; l < h->cfg.levels && l <= h->side_cap; ++l) {
     (void)hipEventRecord(h->ev_join[l], h->side[l]);
     (void)hipStreamWaitEvent(main, h->ev_join[l], 0);
   }
@@ -1376,6 +1386,33 @@ int mvae_bind(mvae_handle* h, int32_t device, float* params, float* reduce_arena
   if (const char* v = getenv("MVAE_GRAPH_SEGMENTS")) h->graph_segments = atoi(v) != 0;
   if (const char* v = getenv("MVAE_LSB_MASK")) h->lsb_mask = atoi(v) != 0;
   if (const char* v = getenv("MVAE_MERGE_SIDE")) h->merge_side = atoi(v) != 0;   // all scales > 0 on ONE side stream
+  {   // issue order of the scales' chains: default the small scales first, scale 0 last; MVAE_ISSUE_ORDER="6,5,4,0,3,1,2" overrides
+    const int L = h->cfg.levels;
+    for (int i = 0; i < L; ++i) h->issue_order[i] = L - 1 - i;
+    // 5 .. 7 scales: a replayed forked graph deals its branches onto the process's 4 hardware queues in creation order (branch i
+    // -> queue i mod 4; in-graph stamps, tools/stamps.py with STAMPS_FREE_RUNNING=1), and a chain dealt onto an occupied queue starts
+    // when the chain ahead of it has finished.  Small-first order put scale 0 -- the step's critical path -- behind scale 4's
+    // whole chain: it started 0.47 ms after the forward's fork and 0.97 ms after the backward's.  Issued FOURTH it has the fourth
+    // queue to itself (the fifth to seventh chains queue behind the three smallest ones): C256-nb bf16 20.08 - 20.22 -> 19.59 -
+    // 19.73 ms (medians, interleaved; 3,2,1,0,6,5,4 / 5,4,3,0,6,1,2 / 4,5,6,0,1,2,3 measure the same).
+    if (L >= 5 && L <= 7) {
+      int n = 0;
+      for (int k = 0; k < 3; ++k) h->issue_order[n++] = L - 1 - k;
+      h->issue_order[n++] = 0;
+      for (int sidx = L - 4; sidx >= 1; --sidx) h->issue_order[n++] = sidx;
+    }
+    if (const char* v = getenv("MVAE_ISSUE_ORDER")) {
+      int tmp[MVAE_MAX_LEVELS], n = 0; bool seen[MVAE_MAX_LEVELS] = {}; bool ok = true;
+      for (const char* p = v; *p && n < MVAE_MAX_LEVELS; ) {
+        char* end = nullptr; const long k = strtol(p, &end, 10);
+        if (end == p) break;
+        if (k < 0 || k >= L || seen[k]) { ok = false; break; }
+        seen[k] = true; tmp[n++] = (int)k; p = (*end == ',') ? end + 1 : end;
+      }
+      if (ok && n == L) for (int i = 0; i < L; ++i) h->issue_order[i] = tmp[i];
+    }
+  }
+  if (const char* v = getenv("MVAE_SIDE_STREAMS")) { const int n = atoi(v); h->side_cap = n < 1 ? 1 : (n > MVAE_MAX_LEVELS - 1 ? MVAE_MAX_LEVELS - 1 : n); }
   if (h->wgrad_streams == 1) h->use_graphs = false;
   // scale 0 (on the caller's stream) is the long pole of every step and the other scales only fill the gaps it leaves,
   // so low-priority side streams look natural -- but they buy 0.4 % on the first handle of a process and cost up to 50 %
@@ -1475,7 +1512,7 @@ int mvae_forward(mvae_handle* h, const mvae_step_io* io, void* stream) {
     fork_scales(h, s);
     PreOp none{nullptr, nullptr, nullptr};
     for (int ord = 0; ord < L; ++ord) {
-      const int si = scale0_first(1) ? ord : L - 1 - ord;
+      const int si = scale0_first(1) ? ord : h->issue_order[ord];
       if (debug_skip_scale(si)) continue;
       hipStream_t ss = scale_stream(h, si, s);
       profiler().cur_scale = si;
@@ -1770,7 +1807,7 @@ static int backward_impl(mvae_handle* h, int phase, float r_factor, float kl_fac
   // (Holding the smaller scales back until scale 0 reaches its MFMA-bound 5x5 convolutions, so that their HBM-bound work
   // would fill those windows, was measured: 5.88 .. 6.05 ms against 5.92 -- their chains are latency-bound and only move
   // the contention.  They start at the fork.)
-  for (int ord = 0; ord < L; ++ord) scale_half(scale0_first(2) ? ord : L - 1 - ord, phase);
+  for (int ord = 0; ord < L; ++ord) scale_half(scale0_first(2) ? ord : h->issue_order[ord], phase);
   join_scales(h, s_main);
   stamp(h, 6, s_main);
   profiler().cur_scale = -1;

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Unperturbed timeline of a train step from in-graph device time stamps (MVAE_STAMPS=1; csrc/runtime.cpp stamp()):
 when each scale's forward / backward chain starts and ends relative to the step start.  GPU box:
-    MVAE_STAMPS=1 python tools/stamps.py [c32nb|c256nb] [batch] [f32|bf16]"""
+    MVAE_STAMPS=1 python tools/stamps.py [c32nb|c256nb] [batch] [f32|bf16]
+STAMPS_FREE_RUNNING=1: the loop never synchronises (as a training loop) and the stamps of its last step are shown -- reading the
+stamps after every step starts each step on an idle device, with the graph launch's node-by-node enqueue visible as late chain starts."""
 import ctypes as C
 import os
 import sys
@@ -23,7 +25,16 @@ eng.set_params(init_params(eng.param_table, 42))
 x = eng.to_device(np.random.default_rng(0).uniform(0, 255, (B,) + tuple(w["input_dims"])).astype(np.float32))
 L = len(w["z_dims"])
 runs = []
-for step in range(30):
+FREE = os.environ.get("STAMPS_FREE_RUNNING", "") == "1"     # no synchronisation between steps: the stamps of the LAST of 60 steps
+if FREE:
+    x = eng.stage_input(x)
+    for step in range(60):
+        eng.train_step(x, 1e-3, 1000.0, 10.0, 1.0, seed=step)
+    eng.sync()
+    buf = (C.c_uint64 * 64)()
+    assert eng.lib.mvae_stamps(eng.h, buf, 64) == 0
+    runs.append(np.array(buf[:], dtype=np.float64))
+for step in range(0 if FREE else 30):
     eng.train_step(x, 1e-3, 1000.0, 10.0, 1.0, seed=step)
     if step >= 20:
         buf = (C.c_uint64 * 64)()
