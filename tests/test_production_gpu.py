@@ -322,3 +322,38 @@ def test_soak_400_steps_stay_finite_and_on_graphs(dt):
     assert eager == 0 and 1 <= captured <= 4, (captured, eager)
     per = np.diff(times) / 100.0
     assert per[1:].max() <= 1.25 * per[1:].min(), per
+
+
+def test_scale0_chain_has_a_hardware_queue_to_itself_c256nb(monkeypatch):
+    """A 7-scale model makes 7 graph branches for the process's 4 hardware queues; the issue order (csrc/runtime.cpp,
+    issue_order) is chosen so that scale 0 -- the step's critical path -- does not queue behind another scale's chain.  In-graph
+    device time stamps of a free-running loop (no synchronisation between steps): scale 0's forward and backward chains
+    begin before ANY other chain has ended.  (With the small-first order they began when scale 4's chain ended: 0.47 ms and
+    0.97 ms after the forks at batch 64.)  Guards the runtime's branch -> queue dealing this relies on."""
+    import ctypes as C
+    monkeypatch.setenv("MVAE_STAMPS", "1")
+    name, B = "c256nb", 16
+    eng = _engine(name, B, act_dtype="bf16")
+    from multiscale_variational_autoencoder_amd.initializers import init_params
+    eng.set_params(init_params(eng.param_table, 42))
+    x = eng.stage_input(eng.to_device(np.random.default_rng(3).uniform(0, 255, (B,) + tuple(CONFIGS[name]["input_dims"])).astype(np.float32)))
+    for step in range(12):
+        eng.train_step(x, 1e-3, 1000.0, 10.0, 1.0, seed=step)
+    eng.sync()
+    buf = (C.c_uint64 * 64)()
+    assert eng.lib.mvae_stamps(eng.h, buf, 64) == 0
+    t = np.array(buf[:], dtype=np.float64)
+    L = len(CONFIGS[name]["z_dims"])
+    us = lambda i: (t[i] - t[0]) / 100.0                       # 100 MHz device clock
+    fwd_begin0, bwd_begin0 = us(10), us(30)
+    first_fwd_end = min(us(20 + l) for l in range(1, L))
+    first_bwd_end = min(us(40 + l) for l in range(1, L))
+    print("scale 0 forward begins %.0f us after the pass start (first other chain ends at %.0f); backward %.0f (%.0f)"
+          % (fwd_begin0, first_fwd_end, bwd_begin0, first_bwd_end))
+    eng.close()
+    assert np.isfinite(t[:50]).all() and fwd_begin0 >= 0 and bwd_begin0 > fwd_begin0       # the stamps themselves are sane
+    if not (fwd_begin0 < first_fwd_end and bwd_begin0 < first_bwd_end):
+        # a scheduling expectation, not a correctness property: report it without stopping a `pytest -x` run
+        pytest.xfail("scale 0 queued behind another scale's chain (forward %.0f >= %.0f or backward %.0f >= %.0f us): this "
+                     "runtime deals graph branches onto hardware queues differently -- set MVAE_ISSUE_ORDER"
+                     % (fwd_begin0, first_fwd_end, bwd_begin0, first_bwd_end))
